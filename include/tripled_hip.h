@@ -1,0 +1,172 @@
+/*
+ * tripled_hip.h -- C ABI of libtripled_hip.so: hand-written CDNA4 (gfx950) kernels for
+ * the self-supervised depth loss hot path.
+ *
+ * The reference (ufukpage/TripleD, pure Python/PyTorch) has NO native interface on this
+ * path; its hot ops are nn.Module methods built from stock ATen calls.  Each entry point
+ * below names the reference code it replaces (paths relative to the reference checkout).
+ * The binding a maintainer of the reference would add is a ctypes stub: INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
+ *   - tensors are dense, NCHW, fp32, row-major (x fastest), exactly as the reference holds them;
+ *   - the caller owns every buffer; the library allocates nothing and keeps no global state;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream); no call synchronises, so every call is legal inside hipGraph capture;
+ *   - return value: TD_OK (0) or a negative TD_ERR_* code; nothing throws across the ABI;
+ *   - n_src = number of non-reference frames (frame_ids[1:]), 1..TD_MAX_SRC;
+ *   - candidate order of the min-reprojection is the reference's: identity terms for
+ *     src 0..n_src-1 first (when automasking), then the warped terms for src 0..n_src-1.
+ */
+#ifndef TRIPLED_HIP_H
+#define TRIPLED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD_ABI_VERSION 1
+#define TD_MAX_SRC 4
+
+#define TD_OK 0
+#define TD_ERR_BAD_ARG (-1)      /* null pointer / non-positive size / n_src out of range */
+#define TD_ERR_UNSUPPORTED (-2)  /* shape the kernels do not cover (e.g. H or W < 3)        */
+#define TD_ERR_LAUNCH (-3)       /* hipGetLastError() != hipSuccess after the launch        */
+#define TD_ERR_WORKSPACE (-4)    /* caller-provided workspace too small                     */
+
+typedef void* td_stream_t;
+
+int td_abi_version(void);
+const char* td_error_string(int code);
+/* Last HIP error text recorded by a failed launch on this thread ("" if none). */
+const char* td_last_hip_error(void);
+
+/* Number of thread blocks td_photo_fwd uses for a B x H x W problem (sizes `partial`), and
+ * the number td_photo_bwd uses (sizes `dP_partial`; its tiles are smaller). */
+int td_photo_num_blocks(int B, int H, int W);
+int td_photo_bwd_num_blocks(int B, int H, int W);
+
+/*
+ * Identity (auto-mask) photometric term, scale independent:
+ *   idloss[b, i, y, x] = 0.85 * mean_c SSIM(src_i, tgt) + 0.15 * mean_c sqrt((tgt - src_i)^2 + 1e-6)
+ * Replaces compute_reprojection_loss(inputs[("color", f, 0)], target) inside the automask loop,
+ * mono/model/mono_fm_joint_inpaint/net.py:101-106 (SSIM: mono/model/mono_fm_joint/layers.py:85-107,
+ * robust_l1 + weights: mono/model/mono_fm_joint/net.py:59-71).  The reference recomputes it per
+ * scale; it does not depend on the scale, so it is computed once per step here.
+ *   tgt     [B,3,H,W]
+ *   src     host array of n_src device pointers, each [B,3,H,W]
+ *   idloss  [B,n_src,H,W] (out)
+ */
+int td_photo_identity(const float* tgt, const float* const* src, int n_src,
+                      int B, int H, int W, float* idloss, td_stream_t stream);
+
+/*
+ * Fused per-scale photometric forward.  Replaces, for one scale,
+ *   generate_images_pred            mono/model/mono_fm_joint/net.py:181-194
+ *     F.interpolate(disp,[H,W],bilinear)            :183
+ *     disp_to_depth                                 :157-162
+ *     Backproject.forward                           mono/model/mono_fm_joint/layers.py:57-61
+ *     Project.forward                               mono/model/mono_fm_joint/layers.py:73-82
+ *     F.grid_sample(img, grid, padding_mode="border")  net.py:193  (bilinear, align_corners=False)
+ *   compute_reprojection_loss (SSIM + robust L1)    mono/model/mono_fm_joint/net.py:67-71
+ *   the automask + torch.cat + torch.min block      mono/model/mono_fm_joint_inpaint/net.py:101-117
+ *
+ *   disp      [B,1,hs,ws]  sigmoid disparity of this scale (any hs<=H, ws<=W)
+ *   P         [n_src,B,3,4]  (K @ T_i)[:, :3, :]  -- formed by the caller (tiny matmul, keeps autograd to T)
+ *   invK      [B,4,4]  (only the upper-left 3x3 block is read, as in the reference)
+ *   idloss    [B,n_src,H,W] from td_photo_identity, or NULL to disable automasking
+ *   noise     [n_src,B,H,W] standard-normal draws (scaled by 1e-5 inside, net.py:105) or NULL
+ *   argmin    [B,H,W] uint8 (out): index into the candidate list (reference: int64 "min_index")
+ *   warped    [n_src,B,3,H,W] (out, nullable): the warped sources, outputs[("color", f, s)]
+ *   min_map   [B,H,W] (out, nullable): per-pixel minimum
+ *   partial   [td_photo_num_blocks] (out): per-block sums of the per-pixel minimum; the loss is
+ *             sum(partial) / (B*H*W) / n_scales  (td_sum_scaled finishes it deterministically)
+ */
+int td_photo_fwd(const float* tgt, const float* const* src, int n_src,
+                 const float* disp, const float* P, const float* invK,
+                 const float* idloss, const float* noise,
+                 int B, int H, int W, int hs, int ws,
+                 float min_depth, float max_depth,
+                 uint8_t* argmin, float* warped, float* min_map, float* partial,
+                 td_stream_t stream);
+
+/*
+ * Backward of td_photo_fwd w.r.t. disp and P (what autograd derives in the reference from the
+ * same lines).  Everything is recomputed in-kernel from the inputs; only argmin is saved.
+ *   gscale    device scalar: d(total)/d(loss_s) as handed over by autograd
+ *   inv_count 1 / (B*H*W*n_scales)  (the mean and the /len(scales) of net.py:117)
+ *   d_up      [B,H,W] (out, workspace): gradient w.r.t. the UPSAMPLED disparity
+ *   dP_partial[td_photo_bwd_num_blocks, n_src*12] (out): per-block partial sums of dL/dP
+ * Follow with td_upsample_adjoint (d_up -> d_disp) and td_reduce_dP.
+ */
+int td_photo_bwd(const float* tgt, const float* const* src, int n_src,
+                 const float* disp, const float* P, const float* invK,
+                 const uint8_t* argmin, int automask,
+                 const float* gscale, float inv_count,
+                 int B, int H, int W, int hs, int ws,
+                 float min_depth, float max_depth,
+                 float* d_up, float* dP_partial, td_stream_t stream);
+
+/* Adjoint of F.interpolate(..., [H,W], mode="bilinear", align_corners=False)
+ * (mono/model/mono_fm_joint/net.py:183): d_up [B,H,W] -> d_disp [B,1,hs,ws].
+ * accumulate != 0 adds into d_disp instead of overwriting it. Gather form, deterministic. */
+int td_upsample_adjoint(const float* d_up, int B, int H, int W, int hs, int ws,
+                        float* d_disp, int accumulate, td_stream_t stream);
+
+/* dP[i,b,:,:] = sum over the blocks of sample b of dP_partial (deterministic tree). */
+int td_reduce_dP(const float* dP_partial, int n_src, int B, int H, int W,
+                 float* dP /* [n_src,B,3,4] */, td_stream_t stream);
+
+/* out[0] = scale * sum(partial[0..n)) ; deterministic single-block tree. */
+int td_sum_scaled(const float* partial, int n, float scale, float* out, td_stream_t stream);
+
+/*
+ * Area (box) down-sampling of the target frame: F.interpolate(img, (h, w), mode='area')
+ * at mono/model/mono_fm_joint/net.py:283 and :311, for integer factors fy = H/h, fx = W/w.
+ *   img [B,C,H,W] -> out [B,C,h,w]
+ */
+int td_area_downsample(const float* img, int B, int C, int H, int W, int h, int w,
+                       float* out, td_stream_t stream);
+
+/* Number of blocks td_smooth_fwd/bwd use for a B x h x w disparity. */
+int td_smooth_num_blocks(int B, int h, int w);
+
+/*
+ * Edge-aware first + second order smoothness, forward.  Replaces
+ *   disp mean-normalisation   mono/model/mono_fm_joint_inpaint/net.py:122-124
+ *   get_smooth_loss + gradient  mono/model/mono_fm_joint/net.py:279-307
+ * (the image is the area-resized target, see td_area_downsample).
+ *   disp    [B,1,h,w]   img [B,3,h,w]
+ *   normalize != 0 applies disp / (mean_hw(disp) + 1e-7) per sample first
+ *   mean    [B] (out): per-sample mean of disp (saved for the backward)
+ *   partial [td_smooth_num_blocks, 6] (out): per-block sums of the six terms
+ *           (dx, dy, dxx, dxy, dyx, dyy); each term's mean uses its own element count.
+ * Finish with td_smooth_finish.
+ */
+int td_smooth_fwd(const float* disp, const float* img, int B, int h, int w, int normalize,
+                  float* mean, float* partial, td_stream_t stream);
+
+/* loss[0] = weight * sum_k (sum_blocks partial[:,k]) / count_k   (count_k = elements of term k). */
+int td_smooth_finish(const float* partial, int B, int h, int w, float weight, float* loss,
+                     td_stream_t stream);
+
+/*
+ * Smoothness backward: d(loss)/d(disp) including the mean-normalisation.
+ *   gscale device scalar upstream gradient; weight as in td_smooth_finish
+ *   g_hat  [B,h,w] (workspace): gradient w.r.t. the normalised disparity
+ *   dot_partial [td_smooth_num_blocks] (workspace): per-block sums of g_hat * disp
+ *   d_disp [B,1,h,w] (out); accumulate != 0 adds into it.
+ */
+int td_smooth_bwd(const float* disp, const float* img, const float* mean,
+                  int B, int h, int w, int normalize,
+                  const float* gscale, float weight,
+                  float* g_hat, float* dot_partial, float* d_disp, int accumulate,
+                  td_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIPLED_HIP_H */

@@ -1,0 +1,160 @@
+"""GPU parity: hand-written HIP photometric kernels (through the C ABI) vs the CPU oracle and
+vs the golden vectors produced by the reference.  Tolerances are stated per assertion."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import geometry, photometric  # noqa: E402
+from tests.util import kitti_K, make_triplet, random_poses, rel_err, smooth_image  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops as o
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return o
+
+
+def _P(K, Ts):
+    return torch.stack([torch.matmul(K, T)[:, :3, :] for T in Ts], 0).contiguous()
+
+
+def _case(seed, B, H, W, hs, ws):
+    g = torch.Generator().manual_seed(seed)
+    fr = make_triplet(g, B, H, W)
+    K, invK = kitti_K(B, H, W)
+    Ts = random_poses(g, B)
+    disp = (0.05 + 0.9 * smooth_image(g, B, 1, max(hs, 8), max(ws, 8))[:, :, :hs, :ws]).contiguous()
+    noise = torch.randn(2, B, H, W, generator=g)
+    return fr, K, invK, Ts, disp, noise
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 70), (1, 16, 64), (3, 33, 129)])
+def test_identity_term(ops, B, H, W):
+    g = torch.Generator().manual_seed(1)
+    fr = make_triplet(g, B, H, W)
+    out = ops.photo_identity(fr[0].cuda(), [fr[-1].cuda(), fr[1].cuda()]).cpu()
+    for i, f in enumerate((-1, 1)):
+        ref = photometric.reprojection_loss(fr[f], fr[0])[:, 0]
+        # SSIM variances cancel to ~1e-7 and are divided by C2 = 9e-4: 5e-5 absolute
+        assert float((out[:, i] - ref).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("B,H,W,hs,ws", [(2, 48, 96, 24, 48), (2, 48, 96, 3, 6), (1, 37, 130, 19, 65),
+                                         (2, 32, 64, 32, 64), (1, 20, 200, 5, 50)])
+@pytest.mark.parametrize("automask", [True, False])
+def test_forward_matches_oracle(ops, B, H, W, hs, ws, automask):
+    fr, K, invK, Ts, disp, noise = _case(7, B, H, W, hs, ws)
+    srcs = [fr[-1], fr[1]]
+    tgt = fr[0]
+    idl = ops.photo_identity(tgt.cuda(), [s.cuda() for s in srcs]) if automask else None
+    loss, argmin, warped = ops.photometric_scale_loss(
+        disp.cuda(), _P(K, Ts).cuda(), tgt.cuda(), [s.cuda() for s in srcs], invK.cuda(), idl,
+        noise.cuda() if automask else None, 0.1, 100.0, 4, keep_warped=True)
+    nz = [noise[0].unsqueeze(1), noise[1].unsqueeze(1)] if automask else None
+    ref_loss, ref_idx, ref_warped = photometric.photometric_scale_loss(
+        tgt, srcs, disp, K, invK, Ts, nz, 0.1, 100.0, automask=automask, n_scales=4)
+    for i in range(2):
+        # coordinate rounding (ulp(x) ~ 1.5e-5 at x = 200) times image slope
+        assert float((warped[i].cpu() - ref_warped[i]).abs().max()) < 1e-4
+    assert (argmin.cpu().long() == ref_idx).float().mean() > 0.995
+    assert abs(float(loss) - float(ref_loss)) < 2e-6 + 1e-5 * abs(float(ref_loss))
+
+
+@pytest.mark.parametrize("B,H,W,hs,ws", [(2, 48, 96, 24, 48), (2, 48, 96, 6, 12), (1, 37, 130, 19, 65),
+                                         (1, 24, 70, 24, 70)])
+@pytest.mark.parametrize("automask", [True, False])
+def test_backward_matches_oracle_autograd(ops, B, H, W, hs, ws, automask):
+    fr, K, invK, Ts, disp, noise = _case(9, B, H, W, hs, ws)
+    srcs = [fr[-1], fr[1]]
+    tgt = fr[0]
+    idl = ops.photo_identity(tgt.cuda(), [s.cuda() for s in srcs]) if automask else None
+    d = disp.cuda().requires_grad_(True)
+    P = _P(K, Ts).cuda().requires_grad_(True)
+    loss, argmin, _ = ops.photometric_scale_loss(d, P, tgt.cuda(), [s.cuda() for s in srcs], invK.cuda(), idl,
+                                                 noise.cuda() if automask else None, 0.1, 100.0, 4)
+    (loss * 3.0).backward()
+
+    dr = disp.clone().requires_grad_(True)
+    Pr = _P(K, Ts).requires_grad_(True)
+    # same selection as the kernel so that near-ties cannot change which branch gets gradient
+    forced = argmin.cpu().long()
+    warped = []
+    for i in range(2):
+        up = geometry.upsample_bilinear(dr, H, W)
+        _, depth = geometry.disp_to_depth(up, 0.1, 100.0)
+        pts = geometry.backproject(depth, invK)
+        cam = torch.matmul(Pr[i], pts)
+        uv = cam[:, :2] / (cam[:, 2:3] + 1e-7)
+        gx = (uv[:, 0].reshape(B, H, W) / (W - 1) - 0.5) * 2
+        gy = (uv[:, 1].reshape(B, H, W) / (H - 1) - 0.5) * 2
+        warped.append(geometry.grid_sample_border(srcs[i], torch.stack([gx, gy], -1)))
+    nz = [noise[0].unsqueeze(1), noise[1].unsqueeze(1)] if automask else None
+    vals, _, _ = photometric.min_reprojection(tgt, srcs, warped, nz, automask, forced_index=forced)
+    (vals.mean() / 4 * 3.0).backward()
+    # gradients: 2e-3 of the tensor's max magnitude (fp32 re-association in a different order)
+    assert rel_err(d.grad, dr.grad) < 2e-3
+    assert rel_err(P.grad, Pr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("scale", [0, 1, 2, 3])
+def test_against_reference_golden(ops, golden_dir, scale):
+    """Directly against vectors produced by the reference's own code (tools/gen_golden.py)."""
+    z = np.load(os.path.join(golden_dir, "photo_scales.npz"))
+    p = "s%d_" % scale
+    T = lambda k: torch.from_numpy(np.ascontiguousarray(z[k]))
+    tgt, srcs = T("color_0"), [T("color_-1"), T("color_1")]
+    K, invK = T("K"), T("inv_K")
+    Ts = [T("T_-1"), T("T_1")]
+    Tc = [t.cuda().requires_grad_(True) for t in Ts]
+    Kc = K.cuda()
+    P = torch.stack([torch.matmul(Kc, t)[:, :3, :] for t in Tc], 0)
+    d = T(p + "disp").cuda().requires_grad_(True)
+    idl = ops.photo_identity(tgt.cuda(), [s.cuda() for s in srcs])
+    noise = T(p + "noise")[:, :, 0].contiguous()
+    loss, argmin, warped = ops.photometric_scale_loss(d, P, tgt.cuda(), [s.cuda() for s in srcs], invK.cuda(),
+                                                      idl, noise.cuda(), 0.1, 100.0, 4, keep_warped=True)
+    assert float((warped[0].cpu() - T(p + "warped_-1")).abs().max()) < 3e-5
+    assert float((warped[1].cpu() - T(p + "warped_1")).abs().max()) < 3e-5
+    assert (argmin.cpu().numpy() == z[p + "min_index"]).mean() > 0.998
+    assert abs(float(loss) - float(z[p + "loss"])) < 1e-6
+    loss.backward()
+    assert rel_err(d.grad, T(p + "d_disp")) < 5e-3
+    assert rel_err(Tc[0].grad, T(p + "d_T_-1")) < 5e-3
+    assert rel_err(Tc[1].grad, T(p + "d_T_1")) < 5e-3
+
+
+def test_full_size_properties(ops):
+    """BASELINE size (B=12, 192x640): determinism, loss parity with the oracle, and the
+    identity-pose property (zero translation/rotation, constant disparity => every warped pixel
+    is the bilinear sample at u*W/(W-1)-0.5)."""
+    B, H, W = 12, 192, 640
+    fr, K, invK, Ts, disp, noise = _case(3, B, H, W, 96, 320)
+    srcs = [fr[-1].cuda(), fr[1].cuda()]
+    tgt = fr[0].cuda()
+    idl = ops.photo_identity(tgt, srcs)
+    P = _P(K, Ts).cuda()
+    run = lambda: ops.photometric_scale_loss(disp.cuda(), P, tgt, srcs, invK.cuda(), idl, noise.cuda(), 0.1, 100.0, 4)
+    l1, a1, _ = run()
+    l2, a2, _ = run()
+    assert float(l1) == float(l2) and bool((a1 == a2).all())   # bit-reproducible
+    nz = [noise[0].unsqueeze(1), noise[1].unsqueeze(1)]
+    ref_loss, ref_idx, _ = photometric.photometric_scale_loss(fr[0], [fr[-1], fr[1]], disp, K, invK, Ts, nz, 0.1, 100.0)
+    assert abs(float(l1) - float(ref_loss)) < 1e-6
+    assert (a1.cpu().long() == ref_idx).float().mean() > 0.995
+    eye = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
+    Pid = _P(K, [eye, eye]).cuda()
+    _, _, w = ops.photometric_scale_loss(torch.full((B, 1, 96, 320), 0.3).cuda(), Pid, tgt, srcs, invK.cuda(),
+                                         None, None, 0.1, 100.0, 4, keep_warped=True)
+    xs = torch.arange(W, dtype=torch.float32) * W / (W - 1) - 0.5
+    ys = torch.arange(H, dtype=torch.float32) * H / (H - 1) - 0.5
+    gx = (xs + 0.5) / W * 2 - 1
+    gy = (ys + 0.5) / H * 2 - 1
+    grid = torch.stack(torch.broadcast_tensors(gx.view(1, 1, W), gy.view(1, H, 1)), -1).repeat(B, 1, 1, 1)
+    expect = geometry.grid_sample_border(fr[-1], grid)
+    assert float((w[0].cpu() - expect).abs().max()) < 2e-4

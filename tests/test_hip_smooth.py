@@ -1,0 +1,55 @@
+"""GPU parity: smoothness / area-downsample kernels vs the CPU oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import smooth  # noqa: E402
+from tests.util import rel_err, smooth_image  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("B,C,H,W,h,w", [(2, 3, 48, 96, 24, 48), (1, 3, 64, 128, 2, 4), (2, 5, 30, 70, 15, 35)])
+def test_area_downsample(ops, B, C, H, W, h, w):
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(B, C, H, W, generator=g)
+    out = ops.area_downsample(img.cuda(), h, w).cpu()
+    assert float((out - smooth.area_resize(img, h, w)).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,h,w", [(2, 24, 48), (1, 3, 3), (3, 17, 131), (2, 6, 12)])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_smooth_forward_backward(ops, B, h, w, normalize):
+    g = torch.Generator().manual_seed(4)
+    disp = (0.05 + 0.9 * smooth_image(g, B, 1, max(h, 8), max(w, 8))[:, :, :h, :w]).contiguous()
+    img = smooth_image(g, B, 3, max(h, 8), max(w, 8))[:, :, :h, :w].contiguous()
+    weight = 1e-3 / 2 / 4
+    d = disp.cuda().requires_grad_(True)
+    loss = ops.smooth_loss(d, img.cuda(), normalize, weight)
+    (loss * 2.0).backward()
+    dr = disp.clone().requires_grad_(True)
+    dn = smooth.mean_normalize(dr) if normalize else dr
+    ref = weight * smooth.smooth_loss(dn, img)
+    (ref * 2.0).backward()
+    assert abs(float(loss) - float(ref)) < 1e-9 + 2e-5 * abs(float(ref))
+    assert rel_err(d.grad, dr.grad) < 1e-3
+
+
+def test_smooth_golden(ops, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    disp = torch.from_numpy(z["smooth_disp"])
+    img = torch.from_numpy(z["img"])
+    im = ops.area_downsample(img.cuda(), disp.shape[2], disp.shape[3])
+    loss = ops.smooth_loss(disp.cuda(), im, False, 1.0)
+    assert abs(float(loss) - float(z["smooth"])) < 2e-5 * abs(float(z["smooth"]))
+    const = ops.smooth_loss(torch.full((1, 1, 8, 8), 0.3).cuda(), im[:1, :, :8, :8].contiguous(), True, 1.0)
+    assert float(const) == 0.0

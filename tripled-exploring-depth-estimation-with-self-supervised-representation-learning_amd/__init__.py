@@ -1,0 +1,27 @@
+"""MI355X-native self-supervised depth training path (TripleD hot path).
+
+The directory name is fixed by the build contract and is not a Python identifier; import it
+through the alias module at the repo root (``import tripled_amd``), which loads this package
+and puts the host-side mirror of the reference interface (``mono``, and the minimal ``mmcv``
+shim when the real mmcv is absent) on ``sys.path``.
+
+Layout
+  csrc/     hand-written HIP kernels for gfx950 + the C ABI (include/tripled_hip.h)
+  lib/      libtripled_hip.so (built in-tree by ``__graft_entry__.build()`` / ``make -C csrc``)
+  native.py ctypes binding of the C ABI (fails loudly when the library is missing)
+  ops.py    torch.autograd.Functions over the C ABI (the fused loss ops)
+  hostside/ ``mono`` (models, apis, core, datasets) and the ``mmcv`` shim
+"""
+import os
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HOSTSIDE = os.path.join(PKG_DIR, "hostside")
+
+
+def _activate():
+    if HOSTSIDE not in sys.path:
+        sys.path.insert(0, HOSTSIDE)
+
+
+_activate()

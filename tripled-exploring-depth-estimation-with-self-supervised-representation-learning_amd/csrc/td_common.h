@@ -1,0 +1,166 @@
+// Shared device helpers for libtripled_hip (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tripled_hip.h"
+
+// Photometric tiles: one 256-thread workgroup (4 waves) per TILE_H x TILE_W output pixels.
+// TILE_W = 64 puts one image row segment on one wave: global reads of a row are a single
+// 256-byte coalesced request and LDS rows are read conflict-free (consecutive banks).
+#define TD_THREADS 256
+#define TD_TILE_W 64
+#define TD_FWD_TILE_H 16
+#define TD_BWD_TILE_H 8
+
+#define TD_SSIM_C1 ((float)(0.01 * 0.01))
+#define TD_SSIM_C2 ((float)(0.03 * 0.03))
+#define TD_L1_EPS2 ((float)(1e-3 * 1e-3))
+
+namespace td {
+
+struct LaunchStatus {
+  static int check(const char* what);
+};
+
+int record_launch_error(hipError_t e, const char* what);
+
+__device__ __forceinline__ int reflect1(int i, int n) {
+  // ReflectionPad2d(1) index map (-1 -> 1, n -> n-2), then clamped so that positions
+  // outside the padded domain (never consumed) still address valid memory.
+  i = i < 0 ? -i : i;
+  i = i >= n ? 2 * n - 2 - i : i;
+  i = i < 0 ? 0 : i;
+  return i >= n ? n - 1 : i;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// Sum over the 256-thread block; result valid in thread 0. `scratch` >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
+  __syncthreads();
+  return r;
+}
+
+// Per-sample camera constants staged once per block.
+struct Cam {
+  float ik[9];                 // inv_K[:3,:3]
+  float P[TD_MAX_SRC][12];     // (K @ T_i)[:3,:]
+};
+
+// Result of projecting one target pixel into one source frame.
+struct Tap {
+  int x0, y0, x1, y1;          // clamped tap coordinates
+  float nw, ne, sw, se;        // ATen bilinear weights
+  bool in_e, in_s;             // east / south taps inside the image (ATen within_bounds)
+  float ix, iy;                // clipped sample coordinate
+  float gmx, gmy;              // clip-gradient multipliers (0 where the coordinate was clipped)
+};
+
+// Bilinear up-sampling of the low-res disparity at full-res pixel (qx,qy), exactly as
+// ATen upsample_bilinear2d with align_corners=False (source index clamped below at 0).
+struct UpIdx {
+  int i0, i1;
+  float l0, l1;
+};
+
+__device__ __forceinline__ UpIdx up_index(int q, float ratio, int n_in) {
+  float s = ratio * ((float)q + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  int i0 = (int)s;
+  i0 = i0 > n_in - 1 ? n_in - 1 : i0;
+  UpIdx r;
+  r.i0 = i0;
+  r.i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+  r.l1 = s - (float)i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+__device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int hs, int ws,
+                                               float ry, float rx, int qy, int qx) {
+  const UpIdx vy = up_index(qy, ry, hs);
+  const UpIdx vx = up_index(qx, rx, ws);
+  const float* r0 = d + (size_t)vy.i0 * ws;
+  const float* r1 = d + (size_t)vy.i1 * ws;
+  return vy.l0 * (vx.l0 * r0[vx.i0] + vx.l1 * r0[vx.i1]) +
+         vy.l1 * (vx.l0 * r1[vx.i0] + vx.l1 * r1[vx.i1]);
+}
+
+// Depth -> camera point -> source pixel -> bilinear taps.  Mirrors the reference's fp32
+// operation sequence (Backproject/Project in layers.py, grid_sampler in ATen) step by step.
+__device__ __forceinline__ Tap project_tap(const float* ik, const float* P, float depth,
+                                           int qx, int qy, int W, int H,
+                                           float* pt /*3: camera point*/, float* cz /*c0,c1,z*/) {
+  const float fx = (float)qx, fy = (float)qy;
+  const float r0 = ik[0] * fx + ik[1] * fy + ik[2];
+  const float r1 = ik[3] * fx + ik[4] * fy + ik[5];
+  const float r2 = ik[6] * fx + ik[7] * fy + ik[8];
+  const float X = depth * r0, Y = depth * r1, Z = depth * r2;
+  pt[0] = X; pt[1] = Y; pt[2] = Z;
+  const float c0 = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+  const float c1 = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+  const float c2 = P[8] * X + P[9] * Y + P[10] * Z + P[11];
+  const float z = c2 + 1e-7f;
+  cz[0] = c0; cz[1] = c1; cz[2] = z;
+  const float u = c0 / z, v = c1 / z;
+  const float gx = (u / (float)(W - 1) - 0.5f) * 2.f;
+  const float gy = (v / (float)(H - 1) - 0.5f) * 2.f;
+  float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+  float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+  Tap t;
+  // clip_coordinates_set_grad: gradient is zero at and beyond the borders
+  t.gmx = (ix > 0.f && ix < (float)(W - 1)) ? 1.f : 0.f;
+  t.gmy = (iy > 0.f && iy < (float)(H - 1)) ? 1.f : 0.f;
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  int x0 = (int)fx0, y0 = (int)fy0;
+  x0 = x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0);
+  y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+  t.x0 = x0; t.y0 = y0;
+  t.in_e = x0 + 1 <= W - 1;
+  t.in_s = y0 + 1 <= H - 1;
+  t.x1 = t.in_e ? x0 + 1 : x0;
+  t.y1 = t.in_s ? y0 + 1 : y0;
+  const float ex = fx0 + 1.f - ix, wx = ix - fx0;   // (ix_se - ix), (ix - ix_nw)
+  const float ey = fy0 + 1.f - iy, wy = iy - fy0;
+  t.nw = ex * ey; t.ne = wx * ey; t.sw = ex * wy; t.se = wx * wy;
+  t.ix = ix; t.iy = iy;
+  return t;
+}
+
+__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, int W, const Tap& t) {
+  const float* r0 = plane + (size_t)t.y0 * W;
+  const float* r1 = plane + (size_t)t.y1 * W;
+  float o = r0[t.x0] * t.nw;
+  if (t.in_e) o += r0[t.x1] * t.ne;
+  if (t.in_s) o += r1[t.x0] * t.sw;
+  if (t.in_e && t.in_s) o += r1[t.x1] * t.se;
+  return o;
+}
+
+// SSIM loss value for one channel from 3x3 window sums (sum of x, y, x^2, y^2, xy).
+__device__ __forceinline__ float ssim_from_sums(float sx, float sy, float sxx, float syy, float sxy) {
+  const float k = 1.f / 9.f;
+  const float mx = sx * k, my = sy * k;
+  const float vx = sxx * k - mx * mx;
+  const float vy = syy * k - my * my;
+  const float cxy = sxy * k - mx * my;
+  const float n = (2.f * mx * my + TD_SSIM_C1) * (2.f * cxy + TD_SSIM_C2);
+  const float d = (mx * mx + my * my + TD_SSIM_C1) * (vx + vy + TD_SSIM_C2);
+  const float s = (1.f - n / d) / 2.f;
+  return fminf(fmaxf(s, 0.f), 1.f);
+}
+
+}  // namespace td

@@ -1,0 +1,102 @@
+"""ctypes binding of libtripled_hip.so (C ABI: include/tripled_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call returns an
+error code, an exception is raised.  Nothing in here touches ``oracle/``.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtripled_hip.so")
+
+TD_MAX_SRC = 4
+_c_float_p = ctypes.c_void_p   # device pointers travel as integers
+_c_u8_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/tripled_hip.h one to one
+_PTRARR = ctypes.POINTER(ctypes.c_void_p)
+_I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+SIGNATURES = {
+    "td_abi_version": (_I, []),
+    "td_error_string": (ctypes.c_char_p, [_I]),
+    "td_last_hip_error": (ctypes.c_char_p, []),
+    "td_photo_num_blocks": (_I, [_I, _I, _I]),
+    "td_photo_bwd_num_blocks": (_I, [_I, _I, _I]),
+    "td_photo_identity": (_I, [_P, _PTRARR, _I, _I, _I, _I, _P, _P]),
+    "td_photo_fwd": (_I, [_P, _PTRARR, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "td_photo_bwd": (_I, [_P, _PTRARR, _I, _P, _P, _P, _P, _I, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "td_upsample_adjoint": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "td_reduce_dP": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "td_sum_scaled": (_I, [_P, _I, _F, _P, _P]),
+    "td_area_downsample": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "td_smooth_num_blocks": (_I, [_I, _I, _I]),
+    "td_smooth_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "td_smooth_finish": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "td_smooth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _P]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and return the ctypes handle; raises NativeLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            "libtripled_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C <package>/csrc`; there is no non-HIP fallback" % path)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (path, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError("%s does not export %s" % (path, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.td_abi_version() != 1:
+        raise NativeLibraryError("ABI version mismatch: library %d, binding 1" % lib.td_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        lib = load()
+        msg = lib.td_error_string(code).decode()
+        hip = lib.td_last_hip_error().decode()
+        raise NativeLibraryError("%s failed: %s (%d)%s" % (what, msg, code, (" [" + hip + "]") if hip else ""))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be a dense CUDA/HIP tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeLibraryError("libtripled_hip needs device tensors (got a %s tensor)" % t.device)
+    if not t.is_contiguous():
+        raise NativeLibraryError("libtripled_hip needs contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,167 @@
+"""torch.autograd.Functions over the C ABI of libtripled_hip.so.
+
+These are the fused replacements for the reference's unfused loss ops; each docstring cites
+the reference lines it stands in for.  All launches go to torch's current HIP stream and do
+not synchronise, so a training step that uses them can be captured in a HIP graph.
+"""
+import torch
+
+from . import native
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def photo_identity(tgt, srcs):
+    """Auto-mask identity term for every source frame, once per step.
+    compute_reprojection_loss(inputs[("color", f, 0)], target) at
+    mono/model/mono_fm_joint_inpaint/net.py:101-104 -> [B, n_src, H, W]."""
+    lib = native.load()
+    tgt = _f32c(tgt)
+    srcs = [_f32c(s) for s in srcs]
+    B, _, H, W = tgt.shape
+    out = torch.empty(B, len(srcs), H, W, device=tgt.device, dtype=torch.float32)
+    native.check(lib.td_photo_identity(native.ptr(tgt), native.ptr_array(srcs), len(srcs), B, H, W,
+                                       native.ptr(out), native.stream()), "td_photo_identity")
+    return out
+
+
+def area_downsample(img, h, w):
+    """F.interpolate(img, (h, w), mode='area') for integer factors
+    (mono/model/mono_fm_joint/net.py:283, :311).  No gradient (the image is an input)."""
+    lib = native.load()
+    img = _f32c(img.detach())
+    B, C, H, W = img.shape
+    if (H, W) == (h, w):
+        return img
+    out = torch.empty(B, C, h, w, device=img.device, dtype=torch.float32)
+    native.check(lib.td_area_downsample(native.ptr(img), B, C, H, W, h, w, native.ptr(out), native.stream()),
+                 "td_area_downsample")
+    return out
+
+
+class _PhotometricScaleLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, P, tgt, srcs, invK, idloss, noise, min_depth, max_depth, n_scales, keep_warped):
+        lib = native.load()
+        disp = _f32c(disp)
+        P = _f32c(P)
+        B, _, H, W = tgt.shape
+        hs, ws = disp.shape[2], disp.shape[3]
+        n_src = len(srcs)
+        dev = tgt.device
+        argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+        nblk = lib.td_photo_num_blocks(B, H, W)
+        partial = torch.empty(nblk, device=dev, dtype=torch.float32)
+        warped = torch.empty(n_src, B, 3, H, W, device=dev, dtype=torch.float32) if keep_warped else None
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_photo_fwd(native.ptr(tgt), native.ptr_array(srcs), n_src, native.ptr(disp),
+                                      native.ptr(P), native.ptr(invK), native.ptr(idloss), native.ptr(noise),
+                                      B, H, W, hs, ws, float(min_depth), float(max_depth),
+                                      native.ptr(argmin), native.ptr(warped), None, native.ptr(partial), st),
+                     "td_photo_fwd")
+        inv_count = 1.0 / (float(B) * H * W * n_scales)
+        native.check(lib.td_sum_scaled(native.ptr(partial), nblk, inv_count, native.ptr(loss), st), "td_sum_scaled")
+        ctx.save_for_backward(disp, P, tgt, invK, argmin, *srcs)
+        ctx.meta = (min_depth, max_depth, inv_count, idloss is not None, n_src)
+        ctx.mark_non_differentiable(argmin)
+        if keep_warped:
+            ctx.mark_non_differentiable(warped)
+            return loss.reshape(()), argmin, warped
+        return loss.reshape(()), argmin, torch.empty(0, device=dev)
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_argmin, _g_warped):
+        lib = native.load()
+        disp, P, tgt, invK, argmin, *srcs = ctx.saved_tensors
+        min_depth, max_depth, inv_count, automask, n_src = ctx.meta
+        B, _, H, W = tgt.shape
+        hs, ws = disp.shape[2], disp.shape[3]
+        dev = tgt.device
+        g = _f32c(g_loss.reshape(1))
+        d_up = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+        nblk = lib.td_photo_bwd_num_blocks(B, H, W)
+        dP_part = torch.empty(nblk, n_src * 12, device=dev, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_photo_bwd(native.ptr(tgt), native.ptr_array(srcs), n_src, native.ptr(disp),
+                                      native.ptr(P), native.ptr(invK), native.ptr(argmin), int(automask),
+                                      native.ptr(g), inv_count, B, H, W, hs, ws, float(min_depth),
+                                      float(max_depth), native.ptr(d_up), native.ptr(dP_part), st),
+                     "td_photo_bwd")
+        d_disp = torch.empty_like(disp)
+        native.check(lib.td_upsample_adjoint(native.ptr(d_up), B, H, W, hs, ws, native.ptr(d_disp), 0, st),
+                     "td_upsample_adjoint")
+        dP = torch.empty_like(P)
+        native.check(lib.td_reduce_dP(native.ptr(dP_part), n_src, B, H, W, native.ptr(dP), st), "td_reduce_dP")
+        return d_disp, dP, None, None, None, None, None, None, None, None, None
+
+
+def photometric_scale_loss(disp, P, tgt, srcs, invK, idloss=None, noise=None, min_depth=0.1,
+                           max_depth=100.0, n_scales=4, keep_warped=False):
+    """One scale of generate_images_pred + automask + min-reprojection
+    (mono/model/mono_fm_joint/net.py:181-194; mono/model/mono_fm_joint_inpaint/net.py:101-117).
+
+    disp [B,1,hs,ws]; P [n_src,B,3,4] = (K @ T)[:, :3, :] per source frame; idloss from
+    photo_identity (None = no automask); noise [n_src,B,H,W] N(0,1) draws or None.
+    Returns (loss = mean(min)/n_scales, argmin uint8 [B,H,W], warped [n_src,B,3,H,W] or empty).
+    """
+    tgt = _f32c(tgt)
+    srcs = tuple(_f32c(s) for s in srcs)
+    invK = _f32c(invK)
+    if idloss is not None:
+        idloss = _f32c(idloss)
+    if noise is not None:
+        noise = _f32c(noise)
+    return _PhotometricScaleLoss.apply(disp, P, tgt, srcs, invK, idloss, noise, min_depth, max_depth,
+                                       n_scales, keep_warped)
+
+
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img, normalize, weight):
+        lib = native.load()
+        disp = _f32c(disp)
+        B, _, h, w = disp.shape
+        dev = disp.device
+        mean = torch.empty(B, device=dev, dtype=torch.float32)
+        nblk = lib.td_smooth_num_blocks(B, h, w)
+        partial = torch.empty(nblk, 6, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_smooth_fwd(native.ptr(disp), native.ptr(img), B, h, w, int(normalize),
+                                       native.ptr(mean), native.ptr(partial), st), "td_smooth_fwd")
+        native.check(lib.td_smooth_finish(native.ptr(partial), B, h, w, float(weight), native.ptr(loss), st),
+                     "td_smooth_finish")
+        ctx.save_for_backward(disp, img, mean)
+        ctx.meta = (bool(normalize), float(weight), nblk)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        lib = native.load()
+        disp, img, mean = ctx.saved_tensors
+        normalize, weight, nblk = ctx.meta
+        B, _, h, w = disp.shape
+        dev = disp.device
+        g = _f32c(g_loss.reshape(1))
+        g_hat = torch.empty(B, h, w, device=dev, dtype=torch.float32)
+        dot = torch.empty(nblk, device=dev, dtype=torch.float32)
+        d_disp = torch.empty_like(disp)
+        native.check(lib.td_smooth_bwd(native.ptr(disp), native.ptr(img), native.ptr(mean), B, h, w,
+                                       int(normalize), native.ptr(g), weight, native.ptr(g_hat),
+                                       native.ptr(dot), native.ptr(d_disp), 0, native.stream()), "td_smooth_bwd")
+        return d_disp, None, None, None
+
+
+def smooth_loss(disp, img_at_scale, normalize=True, weight=1.0):
+    """weight * get_smooth_loss(disp / (mean(disp) + 1e-7), img)
+    (mono/model/mono_fm_joint_inpaint/net.py:122-131, mono/model/mono_fm_joint/net.py:279-307).
+    ``img_at_scale`` is the target area-resized to disp's size (area_downsample)."""
+    img = _f32c(img_at_scale)
+    if img.shape[2:] != disp.shape[2:]:
+        raise ValueError("img_at_scale must already have disp's spatial size")
+    return _SmoothLoss.apply(disp, img, normalize, weight)
