@@ -1,0 +1,124 @@
+"""In-container end-to-end cross-check against the REAL reference model classes (imported from
+/root/reference with the stub recipe of tools/gen_golden.py).  Skipped where the reference
+checkout is absent (the GPU box).  Both models get the same weights (strict state_dict load --
+the checkpoint-key contract), the same inputs and the same recorded auto-mask noise; the
+build's model runs its loss hot path through the oracle backend here (CPU)."""
+import os
+import sys
+
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "mono")), reason="reference checkout not present")
+
+
+class Opt(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _reference_classes():
+    """Import the reference's model modules, return the classes, and restore sys.modules so the
+    build's own ``mono`` package can be imported afterwards."""
+    sys.dont_write_bytecode = True
+    saved = {k: v for k, v in sys.modules.items() if k == "mono" or k.startswith("mono.")}
+    for k in saved:
+        del sys.modules[k]
+    cuda_orig = torch.Tensor.cuda
+    try:
+        from tools import gen_golden
+        gen_golden.install_reference(REF)
+        import importlib
+        inpaint = importlib.import_module("mono.model.mono_fm_joint_inpaint.net")
+        fm = importlib.import_module("mono.model.mono_fm.net")
+        classes = {"mono_fm_joint_inpaint_disentangle": inpaint.mono_fm_joint_inpaint_disentangle,
+                   "mono_fm_joint_inpaint": inpaint.mono_fm_joint_inpaint,
+                   "mono_fm_joint_inpaint_disentangle_distill_sep_colorize":
+                       inpaint.mono_fm_joint_inpaint_disentangle_distill_sep_colorize,
+                   "mono_fm": fm.mono_fm}
+        tap = gen_golden.NoiseTap
+    finally:
+        for k in [k for k in sys.modules if k == "mono" or k.startswith("mono.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return classes, tap, cuda_orig
+
+
+def _options(name, B, H, W):
+    o = Opt(name=name, depth_num_layers=18, pose_num_layers=18, extractor_num_layers=18, frame_ids=[0, -1, 1],
+            imgs_per_gpu=B, height=H, width=W, scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0,
+            depth_pretrained_path=None, pose_pretrained_path=None, extractor_pretrained_path=None,
+            automask=True, disp_norm=True, dis=1e-3, cvt=1e-3, perception_weight=1e-3, smoothness_weight=1e-3,
+            auto_res_weight=5e-3, disentangle_layers=[False, False, False, False, True],
+            skip_connection_multiplier=1, depth_skip_type=None, color_skip_type=None,
+            color_skip_layers=[False] * 4, depth_use_shuffle=False, depth_disentangle_type="use_half",
+            freeze_extractor=False, colorize_num_layers=18, colorize_pretrained_path=None, colorize_weight=1e-2)
+    return o
+
+
+def _inputs(B, H, W):
+    from tests.util import kitti_K, make_triplet
+    g = torch.Generator().manual_seed(0)
+    fr = make_triplet(g, B, H, W)
+    K, iK = kitti_K(B, H, W)
+    inputs = {}
+    for f in (0, -1, 1):
+        inputs[("color", f, 0)] = fr[f]
+        inputs[("color_aug", f, 0)] = (fr[f] * 0.9 + 0.03).contiguous()
+    mask = torch.ones(B, 3, H, W)
+    mask[:, :, 10:26, 30:46] = 0
+    mask[:, :, 50:66, 80:96] = 0
+    inputs[("mask", 0, 0)] = mask
+    inputs["K"], inputs["inv_K"] = K, iK
+    return inputs
+
+
+@pytest.mark.parametrize("name", ["mono_fm_joint_inpaint_disentangle", "mono_fm",
+                                  "mono_fm_joint_inpaint_disentangle_distill_sep_colorize"])
+def test_same_weights_same_losses(name):
+    import tripled_amd  # noqa: F401
+    classes, NoiseTap, cuda_orig = _reference_classes()
+    try:
+        from mono.model import MONO
+        from oracle.backend import OracleLossBackend
+        B, H, W = 2, 96, 128
+        torch.manual_seed(3)
+        ref = classes[name](_options(name, B, H, W))
+        mine = MONO.module_dict[name](_options(name, B, H, W))
+        missing = mine.load_state_dict(ref.state_dict(), strict=True)   # identical checkpoint keys
+        assert not missing.missing_keys and not missing.unexpected_keys
+        mine.set_loss_backend(OracleLossBackend())
+        for m in (ref, mine):
+            m.train()
+            m.DepthDecoder.do.eval()          # dropout is the one RNG consumer we do not replay
+        ref_in = _inputs(B, H, W)
+        with NoiseTap() as tap:
+            ref_out, ref_loss = ref(ref_in)
+        draws = list(tap.draws)
+        mine.set_noise_source(lambda shape, device: draws.pop(0))
+        out, loss = mine(_inputs(B, H, W))
+        assert [str(k) for k in loss] == [str(k) for k in ref_loss]
+        for k in ref_loss:
+            a, b = loss[k].mean(), ref_loss[k].mean()
+            assert abs(float(a) - float(b)) < 1e-6 + 1e-4 * abs(float(b)), (k, float(a), float(b))
+        for s in range(4):
+            assert float((out[("disp", 0, s)] - ref_out[("disp", 0, s)]).abs().max()) < 1e-5
+            assert (out[("min_index", s)] == ref_out[("min_index", s)]).float().mean() > 0.995
+        tot = sum(v.mean() for v in loss.values())
+        ref_tot = sum(v.mean() for v in ref_loss.values())
+        tot.backward()
+        ref_tot.backward()
+        ref_params = dict(ref.named_parameters())
+        checked = 0
+        for n, p in mine.named_parameters():
+            rg = ref_params[n].grad
+            if rg is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+                continue
+            scale = float(rg.abs().max())
+            assert float((p.grad - rg).abs().max()) <= 2e-3 * scale + 1e-9, n
+            checked += 1
+        assert checked > 100
+    finally:
+        torch.Tensor.cuda = cuda_orig

@@ -1,0 +1,239 @@
+"""TripleD model family (reference: mono/model/mono_fm_joint_inpaint/net.py).  Registered here:
+the classes the BASELINE configs name -- ``mono_fm_joint_inpaint`` (base),
+``mono_fm_joint_inpaint_disentangle`` (cfg_kitti_tripleD) and
+``mono_fm_joint_inpaint_disentangle_distill_sep_colorize`` (the all-aux-heads config).  The
+reference's six other ablation classes are out of scope."""
+import argparse
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..registry import MONO
+from ..mono_fm_joint.net import mono_fm_joint
+from ..networks import ColorDecoder, Conv1x1, DepthDecoder, Encoder, IdentityPartial
+from .color_conversions import rgb2lab
+
+
+@MONO.register_module
+class mono_fm_joint_inpaint(mono_fm_joint):
+    """In-painting auto-encoder variant (reference :20-133)."""
+
+    def __init__(self, options):
+        super().__init__(options)
+        self.use_perceptual = True
+        if self.opt.get("freeze_extractor", False):
+            for p in self.Encoder.parameters():
+                p.requires_grad = False
+        if self.opt.perception_weight == 0.0:
+            del self.Encoder
+            del self.Decoder
+            self.use_perceptual = False
+        if self.opt.get("img_reconstruct_weight", 1) == 0 and hasattr(self, "Decoder"):
+            del self.Decoder
+
+    def _autoencode(self, inputs, outputs, masked):
+        if not self.use_perceptual:
+            return None
+        img = inputs[("color", 0, 0)]
+        features = self.Encoder(img * inputs[("mask", 0, 0)] if masked else img)
+        if self.opt.get("img_reconstruct_weight", 1) != 0:
+            outputs.update(self.Decoder(features, 0))
+        return features
+
+    def forward(self, inputs):
+        outputs = self.DepthDecoder(self.DepthEncoder(inputs["color_aug", 0, 0]))
+        if self.training:
+            outputs.update(self.predict_poses(inputs))
+            features = self._autoencode(inputs, outputs, masked=True)
+            return outputs, self.compute_losses(inputs, outputs, features)
+        return outputs
+
+    def _masked_reconstruction(self, inputs, outputs, scale):
+        """reference :80-91: photometric loss of the auto-encoder output against the resized target,
+        averaged over erased pixels (mask == 0)."""
+        opt = self.opt
+        res_img = outputs[("res_img", 0, scale)].float()
+        size = list(res_img.shape[2:])
+        t_rs = F.interpolate(inputs[("color", 0, 0)], size, mode="bilinear", align_corners=False)
+        hole = 1 - F.interpolate(inputs[("mask", 0, 0)], size, mode="bilinear", align_corners=False)
+        loss = self.compute_reprojection_loss(res_img, t_rs)
+        loss = torch.sum(loss * hole) / torch.sum(hole)
+        return loss / len(opt.scales) * opt.get("img_reconstruct_weight", 1)
+
+    def compute_losses(self, inputs, outputs, features):
+        """reference :47-133."""
+        opt = self.opt
+        loss_dict = {}
+        target = inputs[("color", 0, 0)]
+        if features is not None:
+            for i in range(5):
+                loss_dict[("feature_regularization_loss", i)] = \
+                    self.get_feature_regularization_loss(features[i], target) / (2 ** i) / 5
+            outputs = self.generate_features_pred(inputs, outputs)
+            tgt_f = features[0].float()
+            cands = [self.compute_perceptional_loss(tgt_f, outputs[("feature", f, 0)]) for f in opt.frame_ids[1:]]
+            vals, outputs["min_index"] = torch.min(torch.cat(cands, 1), dim=1)
+            loss_dict["min_perceptional_loss"] = opt.perception_weight * vals.mean()
+        ctx = self._begin_step(inputs)
+        for scale in opt.scales:
+            if features is not None and opt.get("img_reconstruct_weight", 1) != 0:
+                loss_dict[("img_reconstruct_loss", scale)] = self._masked_reconstruction(inputs, outputs, scale)
+            self._photometric_scale(ctx, inputs, outputs, scale, loss_dict)
+            self._smooth_scale(ctx, outputs, scale, loss_dict)
+        return loss_dict
+
+
+def _skip_layer(kind, channels, last):
+    """depth_skip_layer_i for a non-disentangled level (reference :423-437).  The attention
+    variants ('ca', 'pa', 'asca') are ablations no BASELINE config selects."""
+    if kind in ("ca", "pa", "asca"):
+        raise NotImplementedError("depth_skip_type=%r is an ablation variant outside the supported configs" % kind)
+    if kind == "1x1" and last:
+        return nn.Sequential(Conv1x1(channels, channels), nn.BatchNorm2d(channels), nn.ELU())
+    return nn.Identity()
+
+
+@MONO.register_module
+class mono_fm_joint_inpaint_disentangle(mono_fm_joint_inpaint):
+    """cfg_kitti_tripleD's model (reference :398-532): the scene embedding of the depth encoder is
+    split channel-wise at the flagged levels; one half feeds the depth decoder, the other the
+    colour decoder, which also receives the predicted disparities."""
+
+    def __init__(self, options):
+        super().__init__(options)
+        opt = self.opt
+        self.depth_skip_type = opt.get("depth_skip_type", "use_half")
+        self.depth_disentangle_type = opt.get("depth_disentangle_type", "use_half")
+        self.color_skip_type = opt.get("color_skip_type", "use_half")
+        self.use_pfp = opt.get("use_pfp", False)
+        enc_ch = self.DepthEncoder.num_ch_enc
+        n_levels = len(opt.disentangle_layers)
+
+        depth_ch = []
+        for ind, split in enumerate(opt.disentangle_layers):
+            c = int(enc_ch[ind])
+            if split:
+                if self.depth_skip_type in ("ca", "pa", "asca"):
+                    _skip_layer(self.depth_skip_type, c, False)
+                if self.depth_disentangle_type == "use_half":
+                    layer = nn.Sequential(IdentityPartial(part_ratio=2, use_right=False))
+                else:
+                    layer = nn.Sequential(Conv1x1(c, c // 2), nn.BatchNorm2d(c // 2), nn.ELU())
+                depth_ch.append(c // 2)
+            else:
+                layer = _skip_layer(self.depth_skip_type, c, ind == n_levels - 1)
+                depth_ch.append(c)
+            setattr(self, "depth_skip_layer_{}".format(ind), layer)
+        self.DepthDecoder = DepthDecoder(depth_ch, opt.get("depth_use_shuffle", False))
+
+        color_ch = []
+        opt["color_skip_layers"] = opt.get("color_skip_layers", (False, False, False, False))
+        if self.color_skip_type == "1x1":
+            ind = 0
+            for ind, on in enumerate(opt.color_skip_layers):
+                c = int(enc_ch[ind])
+                if on:
+                    layer = nn.Sequential(Conv1x1(c, c // 2), nn.BatchNorm2d(c // 2), nn.ELU())
+                    color_ch.append(c // 2)
+                else:
+                    layer = nn.Identity()
+                    color_ch.append(c)
+                setattr(self, "color_skip_layer_{}".format(ind), layer)
+            setattr(self, "color_skip_layer_{}".format(ind + 1), nn.Identity())
+            color_ch.append(int(enc_ch[-1]))
+        else:
+            color_ch = [int(enc_ch[i]) // 2 if split else int(enc_ch[i])
+                        for i, split in enumerate(opt.disentangle_layers)]
+        self.ColorDecoder = ColorDecoder(color_ch, num_output_channels=3,
+                                         skip_connection_multiplier=options.get("skip_connection_multiplier", 1))
+
+    def forward(self, inputs):
+        opt = self.opt
+        scene = self.DepthEncoder(inputs["color_aug", 0, 0])
+        depth_emb = [getattr(self, "depth_skip_layer_{}".format(i))(scene[i])
+                     for i in range(len(opt.disentangle_layers))]
+        outputs = self.DepthDecoder(depth_emb)
+        if not self.training:
+            return outputs
+        if self.color_skip_type == "1x1":
+            n = len(opt.color_skip_layers)
+            color_emb = [getattr(self, "color_skip_layer_{}".format(i))(scene[i]) for i in range(n)]
+            color_emb.append(getattr(self, "color_skip_layer_{}".format(n))(scene[-1]))
+        else:
+            color_emb = [scene[i][:, scene[i].size(1) // 2:] if split else scene[i]
+                         for i, split in enumerate(opt.disentangle_layers)]
+        outputs = self.ColorDecoder(color_emb, outputs, skip_layers=opt.color_skip_layers)
+        if opt.get("use_pfp", False):
+            feats = {f: F.interpolate(inputs["color_aug", f, 0], [192, 640], mode="bilinear", align_corners=False)
+                     for f in opt.frame_ids[1:]}
+            feats[0] = F.interpolate(outputs[("auto_res_img", 0, 0)], [192, 640], mode="bilinear",
+                                     align_corners=False)
+            outputs.update(self.predict_poses(inputs, feats))
+        else:
+            outputs.update(self.predict_poses(inputs))
+        features = self._autoencode(inputs, outputs, masked=False)
+        return outputs, self.compute_losses(inputs, outputs, features)
+
+    def compute_auto_res_loss(self, inputs, outputs):
+        """reference :520-527 -- note: a per-pixel MAP, reduced later by batch_processor's mean."""
+        if not self.opt.auto_res_weight > 0.0:
+            return {}
+        loss = self.compute_perceptional_loss(inputs[("color", 0, 0)], outputs[("auto_res_img", 0, 0)].float())
+        return {"auto_res_loss": loss * self.opt.auto_res_weight}
+
+    def compute_losses(self, inputs, outputs, features):
+        loss_dict = super().compute_losses(inputs, outputs, features)
+        loss_dict.update(self.compute_auto_res_loss(inputs, outputs))
+        return loss_dict
+
+
+@MONO.register_module
+class mono_fm_joint_inpaint_disentangle_distill_sep_colorize(mono_fm_joint_inpaint):
+    """All-aux-heads config (reference :261-329): depth decoder on the left half of the flagged
+    levels plus a separate colourisation network (Lab: L in, ab out) as distillation target."""
+
+    def __init__(self, options):
+        super().__init__(options)
+        opt = self.opt
+        for ind, split in enumerate(opt.disentangle_layers):
+            if split:
+                self.DepthEncoder.num_ch_enc[ind] = self.DepthEncoder.num_ch_enc[ind] // 2
+        self.DepthDecoder = DepthDecoder(self.DepthEncoder.num_ch_enc, opt.get("depth_use_shuffle", False))
+        self.ColorizeEncoder = Encoder(opt.get("colorize_num_layers", 50), opt.colorize_pretrained_path)
+        self.ColorizeDecoder = ColorDecoder(self.ColorizeEncoder.num_ch_enc, num_output_channels=2,
+                                            skip_connection_multiplier=options.get("skip_connection_multiplier", 1))
+        self.to_lab = rgb2lab
+
+    def forward(self, inputs):
+        opt = self.opt
+        scene = self.DepthEncoder(inputs["color_aug", 0, 0])
+        depth_emb = [scene[i][:, :scene[i].size(1) // 2] if split else scene[i]
+                     for i, split in enumerate(opt.disentangle_layers)]
+        outputs = self.DepthDecoder(depth_emb)
+        if not self.training:
+            return outputs
+        outputs.update(self.predict_poses(inputs))
+        lab = self.to_lab(inputs[("color", 0, 0)], argparse.Namespace(l_cent=50.0, l_norm=50.0, ab_norm=110.0))
+        grey = lab[:, 0:1].expand(-1, 3, -1, -1)
+        grey_emb = self.ColorizeEncoder(grey, depth_emb if opt.get("cond_encoder", False) else None)
+        outputs = self.ColorizeDecoder(grey_emb, outputs)
+        inputs["gt_ab"] = lab[:, 1:]
+        features = self._autoencode(inputs, outputs, masked=False)
+        return outputs, self.compute_losses(inputs, outputs, features)
+
+    def compute_colorization_loss(self, inputs, outputs):
+        """reference :310-323."""
+        opt = self.opt
+        if not opt.colorize_weight > 0.0:
+            return {}
+        loss = self.compute_perceptional_loss(inputs["gt_ab"], outputs[("auto_res_img", 0, 0)].float())
+        if opt.get("use_distill_mask", False):
+            hole = 1 - inputs[("mask", 0, 0)][:, 0:1]
+            loss = torch.sum(loss * hole) / torch.sum(hole)
+        return {"distill_colorize_loss": loss * opt.colorize_weight}
+
+    def compute_losses(self, inputs, outputs, features):
+        loss_dict = super().compute_losses(inputs, outputs, features)
+        loss_dict.update(self.compute_colorization_loss(inputs, outputs))
+        return loss_dict

@@ -1,0 +1,483 @@
+"""Convolutional networks of the TripleD / FeatDepth model families, written once here and
+re-exported under the reference's module paths (mono/model/mono_fm_joint/{resnet,depth_encoder,
+depth_decoder,pose_encoder,pose_decoder,encoder,decoder,layers}.py).
+
+Parameter and buffer names are the reference's (they are the checkpoint keys, SURVEY.md
+section 5): e.g. ``DepthEncoder.encoder.layer1.0.conv1.weight``, ``DepthDecoder.reduce4.conv.weight``,
+``DepthDecoder.crp4.0.1_pointwise.conv.weight``, ``Decoder.upconv5.conv.conv.weight``.
+
+The convolutions are the one dense contraction of the step; they run on MFMA through
+PyTorch-ROCm (MIOpen / hipBLASLt) under bf16 autocast with channels_last activations.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BatchNorm = nn.BatchNorm2d
+
+# (block kind, blocks per stage)  -- reference: mono/model/mono_fm_joint/resnet.py:147-187
+RESNET_SPECS = {18: ("basic", (2, 2, 2, 2)), 34: ("basic", (3, 4, 6, 3)),
+                50: ("bottleneck", (3, 4, 6, 3)), 101: ("bottleneck", (3, 4, 23, 3))}
+
+
+def _conv(cin, cout, k, stride=1, pad=0, bias=False):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias)
+
+
+class BasicBlock(nn.Module):
+    """Two 3x3 convs + identity (reference: resnet.py:18-49)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, use_residual=True):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 3, stride, 1)
+        self.bn1 = BatchNorm(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv(planes, planes, 3, 1, 1)
+        self.bn2 = BatchNorm(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self.use_residual = use_residual
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        if self.use_residual:
+            y = y + (x if self.downsample is None else self.downsample(x))
+        return self.relu(y)
+
+
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (strided) -> 1x1 x4 (reference: resnet.py:52-86)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1)
+        self.bn1 = BatchNorm(planes)
+        self.conv2 = _conv(planes, planes, 3, stride, 1)
+        self.bn2 = BatchNorm(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = BatchNorm(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        y = y + (x if self.downsample is None else self.downsample(x))
+        return self.relu(y)
+
+
+class ResNet(nn.Module):
+    """torchvision-layout ResNet trunk (reference: resnet.py:89-144).  ``avgpool``/``fc`` exist
+    only so that ImageNet / reference checkpoints load with matching keys; the encoders never
+    call them."""
+
+    def __init__(self, block, layers, num_classes=1000, in_channels=3):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = _conv(in_channels, 64, 7, 2, 3)
+        self.bn1 = BatchNorm(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        init_resnet_weights(self)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        out_ch = planes * block.expansion
+        shortcut = None
+        if stride != 1 or self.inplanes != out_ch:
+            shortcut = nn.Sequential(_conv(self.inplanes, out_ch, 1, stride), BatchNorm(out_ch))
+        stage = [block(self.inplanes, planes, stride, shortcut)]
+        self.inplanes = out_ch
+        stage += [block(out_ch, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*stage)
+
+    def stem(self, x):
+        return self.relu(self.bn1(self.conv1(x)))
+
+    def pyramid(self, x, extra=None):
+        """The five feature maps every encoder here exposes (strides 2, 4, 8, 16, 32);
+        ``extra`` optionally adds a conditioning tensor to each level (Encoder.forward)."""
+        if extra is None:
+            f0 = self.stem(x)
+            f1 = self.layer1(self.maxpool(f0))
+            f2 = self.layer2(f1)
+            f3 = self.layer3(f2)
+            return [f0, f1, f2, f3, self.layer4(f3)]
+        f0 = self.stem(x) + extra[0]
+        f1 = self.layer1(self.maxpool(f0)) + extra[1]
+        f2 = self.layer2(f1) + extra[2]
+        f3 = self.layer3(f2) + extra[3]
+        f4 = self.layer4(f3) + extra[4]
+        return [f0, f1, f2, f3, f4]
+
+    def forward(self, x):
+        return self.pyramid(x)[-1]
+
+
+def init_resnet_weights(net):
+    for m in net.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+def build_resnet(num_layers, in_channels=3):
+    if num_layers not in RESNET_SPECS:
+        raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+    kind, layers = RESNET_SPECS[num_layers]
+    return ResNet(BasicBlock if kind == "basic" else Bottleneck, list(layers), in_channels=in_channels)
+
+
+def resnet18(pretrained_path=None):
+    return _maybe_load(build_resnet(18), pretrained_path)
+
+
+def resnet34(pretrained_path=None, **kw):
+    return _maybe_load(build_resnet(34), pretrained_path, "resnet34.pth")
+
+
+def resnet50(pretrained_path=None, **kw):
+    return _maybe_load(build_resnet(50), pretrained_path, "resnet50.pth")
+
+
+def resnet101(pretrained_path=None, **kw):
+    return _maybe_load(build_resnet(101), pretrained_path, "resnet101.pth")
+
+
+def _maybe_load(net, path, fname=None):
+    if path is not None:
+        import os
+        full = os.path.join(path, fname) if fname else path
+        net.load_state_dict(torch.load(full, map_location="cpu", weights_only=True))
+    return net
+
+
+def enc_channels(num_layers):
+    ch = np.array([64, 64, 128, 256, 512])
+    if num_layers > 34:
+        ch[1:] *= 4
+    return ch
+
+
+def _load_encoder_weights(net, path, n_images=1):
+    state = torch.load(path, map_location="cpu", weights_only=True)
+    if n_images > 1:   # reference: pose_encoder.py:45-48
+        state["conv1.weight"] = torch.cat([state["conv1.weight"]] * n_images, 1) / n_images
+    net.load_state_dict(state, strict=False)
+
+
+class DepthEncoder(nn.Module):
+    """ImageNet-normalised ResNet pyramid (reference: depth_encoder.py:8-43)."""
+
+    def __init__(self, num_layers, pretrained_path=None):
+        super().__init__()
+        self.num_ch_enc = enc_channels(num_layers)
+        self.encoder = build_resnet(num_layers)
+        if pretrained_path is not None:
+            _load_encoder_weights(self.encoder, pretrained_path)
+
+    def forward(self, input_image):
+        self.features = self.encoder.pyramid((input_image - 0.45) / 0.225)
+        return self.features
+
+
+class PoseEncoder(nn.Module):
+    """ResNet over the channel-concatenated frame pair (reference: pose_encoder.py:52-92)."""
+
+    def __init__(self, num_layers, pretrained_path=None, num_input_images=2):
+        super().__init__()
+        self.num_ch_enc = enc_channels(num_layers)
+        self.encoder = build_resnet(num_layers, in_channels=3 * num_input_images)
+        if pretrained_path is not None:
+            _load_encoder_weights(self.encoder, pretrained_path, num_input_images)
+
+    def forward(self, input_image):
+        self.features = self.encoder.pyramid((input_image - 0.45) / 0.225)
+        return self.features
+
+
+class Encoder(nn.Module):
+    """Feature extractor of the auto-encoder branch: un-normalised input, optional additive
+    conditioning per level (reference: encoder.py:8-46)."""
+
+    def __init__(self, num_layers, pretrained_path=None):
+        super().__init__()
+        self.num_ch_enc = enc_channels(num_layers)
+        self.encoder = build_resnet(num_layers)
+        if pretrained_path is not None:
+            _load_encoder_weights(self.encoder, pretrained_path)
+        self.features = []
+
+    def forward(self, input_image, input_features=None):
+        self.features = self.encoder.pyramid(input_image, input_features)
+        return self.features
+
+    def stem_only(self, input_image):
+        """features[0] alone (what generate_features_pred consumes)."""
+        return self.encoder.stem(input_image)
+
+
+class PoseDecoder(nn.Module):
+    """1x1 squeeze, two 3x3, 1x1 -> 6; spatial mean * 0.01 (reference: pose_decoder.py:5-26)."""
+
+    def __init__(self, num_ch_enc, stride=1):
+        super().__init__()
+        self.reduce = nn.Conv2d(int(num_ch_enc[-1]), 256, 1)
+        self.conv1 = nn.Conv2d(256, 256, 3, stride, 1)
+        self.conv2 = nn.Conv2d(256, 256, 3, stride, 1)
+        self.conv3 = nn.Conv2d(256, 6, 1)
+        self.relu = nn.ReLU()
+
+    def forward(self, input_features):
+        x = self.relu(self.reduce(input_features[-1]))
+        x = self.relu(self.conv1(x))
+        x = self.relu(self.conv2(x))
+        x = self.conv3(x).float()
+        x = 0.01 * x.mean(3).mean(2).view(-1, 1, 1, 6)
+        return x[..., :3], x[..., 3:]
+
+
+# ---------------------------------------------------------------------------
+# decoder building blocks (reference: layers.py:110-215)
+
+def upsample(x):
+    return F.interpolate(x, scale_factor=2, mode="nearest")
+
+
+class Conv1x1(nn.Module):
+    def __init__(self, in_channels, out_channels, bias=False):
+        super().__init__()
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), kernel_size=1, stride=1, bias=bias)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Conv3x3(nn.Module):
+    """3x3 conv after a 1-pixel reflection (or zero) pad."""
+
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super().__init__()
+        self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+
+    def forward(self, x):
+        return self.conv(self.pad(x))
+
+
+class Conv5x5(nn.Module):
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super().__init__()
+        self.pad = nn.ReflectionPad2d(2) if use_refl else nn.ZeroPad2d(2)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 5)
+
+    def forward(self, x):
+        return self.conv(self.pad(x))
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = Conv3x3(in_channels, out_channels)
+        self.nonlin = nn.ELU(inplace=True)
+
+    def forward(self, x):
+        return self.nonlin(self.conv(x))
+
+
+class CRPBlock(nn.Module):
+    """Chained residual pooling: n x (5x5 max-pool -> 1x1 conv), running sum
+    (reference: layers.py:200-215).  Sub-module names '<i>_pointwise' are checkpoint keys."""
+
+    def __init__(self, in_planes, out_planes, n_stages):
+        super().__init__()
+        for i in range(n_stages):
+            setattr(self, "{}_{}".format(i + 1, "pointwise"),
+                    Conv1x1(in_planes if i == 0 else out_planes, out_planes, False))
+        self.stride = 1
+        self.n_stages = n_stages
+        self.maxpool = nn.MaxPool2d(kernel_size=5, stride=1, padding=2)
+
+    def forward(self, x):
+        top = x
+        for i in range(self.n_stages):
+            top = getattr(self, "{}_{}".format(i + 1, "pointwise"))(self.maxpool(top))
+            x = top + x
+        return x
+
+
+def upshuffle(in_planes, upscale_factor):
+    """Sub-pixel x2 up-sampler (reference: layers.py:130-141), ICNR-style initialisation."""
+    block = nn.Sequential(nn.ReflectionPad2d(1),
+                          nn.Conv2d(in_planes, in_planes * upscale_factor ** 2, 3, 1, 0),
+                          nn.PixelShuffle(upscale_factor), nn.ELU(inplace=True))
+    r2 = upscale_factor ** 2
+    w = block[1].weight
+    sub = torch.empty(w.shape[0] // r2, w.shape[1], w.shape[2], w.shape[3])
+    nn.init.kaiming_normal_(sub)
+    with torch.no_grad():
+        w.copy_(sub.repeat_interleave(r2, dim=0))
+    return block
+
+
+class DepthDecoder(nn.Module):
+    """CRP disparity decoder (reference: depth_decoder.py:8-115): four stages from 1/32 to 1/4
+    resolution, each up-sampled x2 before its sigmoid disparity head, so ("disp", 0, s) has
+    1/2^(s+1) of the input resolution."""
+
+    def __init__(self, num_ch_enc, use_shuffle=False):
+        super().__init__()
+        width, stages = 256, 4
+        self.do = nn.Dropout(p=0.5)
+        self.use_shuffle = use_shuffle
+        if use_shuffle:
+            for i in (1, 2, 3, 4):
+                setattr(self, "up%d" % i, upshuffle(width, 2))
+        self.reduce4 = Conv1x1(num_ch_enc[4], 512, bias=False)
+        self.reduce3 = Conv1x1(num_ch_enc[3], width, bias=False)
+        self.reduce2 = Conv1x1(num_ch_enc[2], width, bias=False)
+        self.reduce1 = Conv1x1(num_ch_enc[1], width, bias=False)
+        self.iconv4 = Conv3x3(512, width)
+        self.iconv3 = Conv3x3(width * 2 + 1, width)
+        self.iconv2 = Conv3x3(width * 2 + 1, width)
+        self.iconv1 = Conv3x3(width * 2 + 1, width)
+        for i in (4, 3, 2, 1):
+            setattr(self, "crp%d" % i, nn.Sequential(CRPBlock(width, width, stages)))
+        for i in (4, 3, 2, 1):
+            setattr(self, "merge%d" % i, Conv3x3(width, width))
+        for i in (4, 3, 2, 1):
+            setattr(self, "disp%d" % i, nn.Sequential(Conv3x3(width, 1), nn.Sigmoid()))
+
+    def _stage(self, i, x):
+        x = F.leaky_relu(getattr(self, "iconv%d" % i)(x))
+        x = getattr(self, "crp%d" % i)(x)
+        x = F.leaky_relu(getattr(self, "merge%d" % i)(x))
+        if self.use_shuffle:
+            # the reference up-samples stage 1 with up2 (depth_decoder.py:105), kept as is
+            x = getattr(self, "up%d" % (2 if i == 1 else i))(x)
+        else:
+            x = upsample(x)
+        return x, getattr(self, "disp%d" % i)(x)
+
+    def forward(self, input_features, frame_id=0):
+        _, l1, l2, l3, l4 = input_features
+        l4 = self.do(l4)
+        l3 = self.do(l3)
+        x, d4 = self._stage(4, self.reduce4(l4))
+        x, d3 = self._stage(3, torch.cat((self.reduce3(l3), x, d4), 1))
+        x, d2 = self._stage(2, torch.cat((self.reduce2(l2), x, d3), 1))
+        x, d1 = self._stage(1, torch.cat((self.reduce1(l1), x, d2), 1))
+        self.outputs = {("disp", frame_id, 3): d4, ("disp", frame_id, 2): d3,
+                        ("disp", frame_id, 1): d2, ("disp", frame_id, 0): d1}
+        return self.outputs
+
+
+class Decoder(nn.Module):
+    """Auto-encoder image decoder: 5 x (conv, x2 nearest, conv), RGB heads at 4 scales
+    (reference: decoder.py:7-57)."""
+    out_key = "res_img"
+
+    def __init__(self, num_ch_enc, num_output_channels=3, num_ch_dec=(16, 32, 64, 128, 256)):
+        super().__init__()
+        self.num_ch_dec = num_ch_dec
+        d = num_ch_dec
+        self.upconv5 = ConvBlock(num_ch_enc[4], d[4])
+        self.upconv4 = ConvBlock(d[4], d[3])
+        self.upconv3 = ConvBlock(d[3], d[2])
+        self.upconv2 = ConvBlock(d[2], d[1])
+        self.upconv1 = ConvBlock(d[1], d[0])
+        self.iconv5 = ConvBlock(d[4], d[4])
+        self.iconv4 = ConvBlock(d[3], d[3])
+        self.iconv3 = ConvBlock(d[2], d[2])
+        self.iconv2 = ConvBlock(d[1], d[1])
+        self.iconv1 = ConvBlock(d[0], d[0])
+        self.disp4 = Conv3x3(d[3], num_output_channels)
+        self.disp3 = Conv3x3(d[2], num_output_channels)
+        self.disp2 = Conv3x3(d[1], num_output_channels)
+        self.disp1 = Conv3x3(d[0], num_output_channels)
+        self.sigmoid = nn.Sigmoid()
+
+    def _heads(self, outputs, key, frame_id, i4, i3, i2, i1):
+        outputs[(key, frame_id, 3)] = self.sigmoid(self.disp4(i4))
+        outputs[(key, frame_id, 2)] = self.sigmoid(self.disp3(i3))
+        outputs[(key, frame_id, 1)] = self.sigmoid(self.disp2(i2))
+        outputs[(key, frame_id, 0)] = self.sigmoid(self.disp1(i1))
+        return outputs
+
+    def forward(self, input_features, frame_id=0):
+        x = self.iconv5(upsample(self.upconv5(input_features[4])))
+        i4 = self.iconv4(upsample(self.upconv4(x)))
+        i3 = self.iconv3(upsample(self.upconv3(i4)))
+        i2 = self.iconv2(upsample(self.upconv2(i3)))
+        i1 = self.iconv1(upsample(self.upconv1(i2)))
+        self.outputs = self._heads({}, "res_img", frame_id, i4, i3, i2, i1)
+        return self.outputs
+
+
+class ColorDecoder(Decoder):
+    """Colour (disentangled) decoder: the Decoder trunk with the predicted disparities added
+    into its feature maps and optional encoder skips (reference: decoder.py:60-112)."""
+
+    def __init__(self, num_ch_enc, num_output_channels=3, skip_connection_multiplier=1):
+        super().__init__(num_ch_enc, num_output_channels, num_ch_dec=(16, 32, 64, 128, 256))
+        self.skip_connection_multiplier = skip_connection_multiplier
+        d = self.num_ch_dec
+        self.upconv5_skip = ConvBlock(num_ch_enc[3], d[3])
+        self.upconv4_skip = ConvBlock(num_ch_enc[2], d[2])
+        self.upconv3_skip = ConvBlock(num_ch_enc[1], d[1])
+        self.upconv2_skip = ConvBlock(num_ch_enc[0], d[0])
+
+    def forward(self, input_features, outputs=None, frame_id=0, skip_layers=(None, None, None, None)):
+        e1, e2, e3, e4, e5 = input_features
+        m = self.skip_connection_multiplier
+
+        def with_disp(x, scale):
+            dsp = F.interpolate(outputs[("disp", frame_id, scale)], list(x.shape[2:]), mode="bilinear",
+                                align_corners=False)
+            return dsp * m
+
+        u5 = upsample(self.upconv5(e5))
+        i5 = self.iconv5(u5) + with_disp(u5, 3)
+        u4 = upsample(self.upconv4(i5))
+        if skip_layers[0]:
+            u4 = u4 + upsample(self.upconv5_skip(e4))
+        i4 = self.iconv4(u4) + with_disp(u4, 2)
+        u3 = upsample(self.upconv3(i4))
+        if skip_layers[1]:
+            u3 = u3 + upsample(self.upconv4_skip(e3))
+        i3 = self.iconv3(u3) + with_disp(u3, 1)
+        u2 = upsample(self.upconv2(i3))
+        if skip_layers[2]:
+            u2 = u2 + upsample(self.upconv3_skip(e2))
+        i2 = self.iconv2(u2) + with_disp(u2, 0)
+        u1 = upsample(self.upconv1(i2))
+        if skip_layers[3]:
+            u1 = u1 + upsample(self.upconv2_skip(e1))
+        i1 = self.iconv1(u1)
+        return self._heads(outputs, "auto_res_img", frame_id, i4, i3, i2, i1)
+
+
+class IdentityPartial(nn.Module):
+    """Keeps the left (or right) 1/part_ratio of the channels (reference: layers.py:392-406)."""
+
+    def __init__(self, part_ratio=2, use_right=True):
+        super().__init__()
+        self.part_ratio = part_ratio
+        self.use_right = use_right
+
+    def forward(self, embedding):
+        cut = embedding.size(1) // self.part_ratio
+        return embedding[:, cut:] if self.use_right else embedding[:, :cut]
