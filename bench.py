@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Benchmark of the BASELINE metric: training images/s of cfg_kitti_tripleD (ResNet50 depth +
+feature nets, ResNet18 pose net, 192x640, 12 images per GPU) on 1..8 MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward (depth/pose/auto-encoder nets under bf16 autocast, channels_last; the loss hot
+path in the hand-written fp32 HIP kernels) + backward + gradient sync (bucketed RCCL all-reduce
+overlapped with backward when N > 1) + grad-clip + Adam, on synthetic frame triplets already
+resident in HBM.  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the field
+definitions (roofline = the dominant hand-written kernel timed live with HIP events;
+cpu_baseline = the same training step with the CPU oracle loss path on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import tripled_amd  # noqa: F401,E402
+from mmcv import Config  # noqa: E402
+from mono.datasets.synthetic import synthetic_batch  # noqa: E402
+from mono.model import MONO  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+# algorithmic bytes per full-resolution pixel of one fused photometric launch at scale s
+# (SURVEY.md section 8d): fwd reads target 12 B + two sources 24 B + disp 4/4^(s+1) B and writes
+# the 1-byte arg-min; bwd re-reads the same, reads the arg-min and writes d(disp) 4/4^(s+1) B.
+def photo_fwd_bytes_per_px(s):
+    return 12 + 24 + 4.0 / 4 ** (s + 1) + 1
+
+
+def photo_bwd_bytes_per_px(s):
+    return 12 + 24 + 4.0 / 4 ** (s + 1) + 1 + 4.0 / 4 ** (s + 1)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--config", default=os.path.join(ROOT, "config", "cfg_kitti_tripleD.py"))
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no-graph", action="store_true", help="do not capture the step in a HIP graph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-batch", type=int, default=2)
+    p.add_argument("--cpu-steps", type=int, default=3)
+    p.add_argument("--syncbn", default="config", choices=["config", "on", "off"])
+    p.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    return p.parse_args()
+
+
+def build_model(cfg, device, channels_last):
+    model = MONO.module_dict[cfg.model["name"]](cfg.model)
+    model = model.to(device)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    model.train()
+    return model
+
+
+class TrainStep:
+    """zero-grad -> forward -> sum of loss means -> backward -> clip -> Adam (what the Runner's
+    batch_processor + DistOptimizerHook do per iteration, mono/apis/trainer.py:32-60,
+    mono/core/utils/dist_utils.py:54-60)."""
+
+    def __init__(self, model, cfg, batch, autocast_dtype):
+        self.model, self.batch, self.dtype = model, batch, autocast_dtype
+        inner = model.module if hasattr(model, "module") else model
+        self.params = [p for p in inner.parameters() if p.requires_grad]
+        ocfg = dict(cfg.optimizer)
+        assert ocfg.pop("type") == "Adam"
+        self.optimizer = torch.optim.Adam(self.params, capturable=torch.cuda.is_available() and batch["K"].is_cuda,
+                                          foreach=True, **ocfg)
+        clip = cfg.optimizer_config.get("grad_clip", None)
+        self.max_norm = clip["max_norm"] if clip else None
+        self.reducer = getattr(model, "reducer", None)
+        self.loss = None
+
+    def __call__(self):
+        if self.reducer is None:
+            self.optimizer.zero_grad(set_to_none=True)   # with the DP engine, forward() re-zeroes the flat buffer
+        with torch.autocast("cuda" if self.batch["K"].is_cuda else "cpu", dtype=self.dtype,
+                            enabled=self.dtype is not None):
+            outputs, losses = self.model(dict(self.batch))
+        total = sum(v.float().mean() for v in losses.values())
+        total.backward()
+        if self.max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=2, foreach=True)
+        self.optimizer.step()
+        self.loss = total.detach()
+        return self.loss
+
+
+def time_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters * 1e-3     # seconds per launch
+
+
+def roofline_of_hot_kernels(cfg, batch):
+    """Time the hand-written photometric kernels in isolation on the benchmark's own inputs
+    (launched on torch's current stream, bracketed by HIP events on that stream)."""
+    from tripled_amd import native
+    lib = native.load()
+    m = cfg.model
+    B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
+    dev = batch["K"].device
+    tgt = batch[("color", 0, 0)].contiguous()
+    srcs = [batch[("color", f, 0)].contiguous() for f in m["frame_ids"][1:]]
+    n_src = len(srcs)
+    invK = batch["inv_K"].contiguous()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    T = torch.eye(4).repeat(B, 1, 1)
+    T[:, :3, 3] = 0.05 * torch.randn(B, 3, generator=g)
+    P = torch.stack([torch.matmul(batch["K"].cpu(), T)[:, :3, :]] * n_src, 0).contiguous().to(dev)
+    idloss = torch.empty(B, n_src, H, W, device=dev)
+    noise = torch.randn(n_src, B, H, W, device=dev)
+    argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+    part = torch.empty(lib.td_photo_num_blocks(B, H, W), device=dev)
+    d_up = torch.empty(B, H, W, device=dev)
+    dpp = torch.empty(lib.td_photo_bwd_num_blocks(B, H, W), n_src * 12, device=dev)
+    gs = torch.ones(1, device=dev)
+    st = native.stream()
+    sp = native.ptr_array(srcs)
+    native.check(lib.td_photo_identity(native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "identity")
+    out = {}
+    px = B * H * W
+    for s in (0,):
+        hs, ws = H >> (s + 1), W >> (s + 1)
+        disp = (0.1 + 0.8 * torch.rand(B, 1, hs, ws, device=dev)).contiguous()
+
+        def fwd():
+            native.check(lib.td_photo_fwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+                                          native.ptr(idloss), native.ptr(noise), B, H, W, hs, ws, 0.1, 100.0,
+                                          native.ptr(argmin), None, None, native.ptr(part), st), "fwd")
+
+        def bwd():
+            native.check(lib.td_photo_bwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+                                          native.ptr(argmin), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
+                                          0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
+
+        t_f, t_b = time_kernel(fwd), time_kernel(bwd)
+        out["photo_fwd_s%d" % s] = dict(seconds=t_f, bytes=photo_fwd_bytes_per_px(s) * px)
+        out["photo_bwd_s%d" % s] = dict(seconds=t_b, bytes=photo_bwd_bytes_per_px(s) * px)
+    return out
+
+
+def cpu_baseline(cfg_path, batch_size, steps):
+    """The same training step on the host: fp32 networks + the CPU oracle loss path (a port of
+    the reference's unfused PyTorch ops, pinned against the reference in tests/)."""
+    from oracle.backend import OracleLossBackend
+    cfg = Config.fromfile(cfg_path)
+    cfg.model["imgs_per_gpu"] = batch_size
+    torch.manual_seed(1024)
+    model = build_model(cfg, torch.device("cpu"), channels_last=False)
+    model.set_loss_backend(OracleLossBackend())
+    batch = synthetic_batch(batch_size, cfg.model["height"], cfg.model["width"], seed=1000,
+                            frame_ids=tuple(cfg.model["frame_ids"]))
+    step = TrainStep(model, cfg, batch, None)
+    step()                      # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = time.time() - t0
+    return dict(value=round(batch_size * steps / dt, 4), unit="imgs/s", cores=torch.get_num_threads(), kind="port",
+                sample="%s fp32 on CPU, B=%d of the %dx%d batch, 1 warm-up + %d timed steps (fwd+bwd+clip+Adam), "
+                       "oracle loss path" % (cfg.model["name"], batch_size, cfg.model["height"], cfg.model["width"], steps))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the loss hot path has no CPU implementation in the product)")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    cfg = Config.fromfile(args.config)
+    m = cfg.model
+    B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
+    torch.manual_seed(1024)
+    model = build_model(cfg, dev, channels_last=True)
+    use_syncbn = {"config": bool(cfg.get("syncbn", False)), "on": True, "off": False}[args.syncbn]
+    if world > 1:
+        from mmcv.parallel import MMDistributedDataParallel
+        if use_syncbn:
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = MMDistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
+                                          find_unused_parameters=cfg.get("find_unused_parameters", False))
+        model.train()
+    batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]))
+    dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    step = TrainStep(model, cfg, batch, dtype)
+
+    # warm-up (and capture) on a side stream: autograd's AccumulateGrad nodes then belong to a
+    # non-default stream, which whole-step graph capture requires
+    graph, graphed = None, False
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(args.warmup, 1)):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if not args.no_graph and world == 1:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            step.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                step()
+            graph.replay()
+            torch.cuda.synchronize()
+            graphed = True
+        except Exception as e:      # capture is an optimisation; report and continue eagerly
+            if rank == 0:
+                print("HIP graph capture unavailable (%s: %s); timing eager launches" % (type(e).__name__, e),
+                      file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    run = graph.replay if graphed else step
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(step.loss)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "train imgs/sec at KITTI 192x640 bs=12/GPU",
+            "value": round(world * B * args.steps / elapsed, 3),
+            "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 convs (MFMA) + f32 loss kernels" if dtype is not None else "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s %dx%d bs=%d/GPU (%s), fwd+bwd+clip+Adam" % (
+                m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
+                "parallelism": "dp%d" % world, "hip_graph": graphed,
+                "syncbn": bool(use_syncbn and world > 1), "final_loss": round(final_loss, 6)},
+        }
+        kern = roofline_of_hot_kernels(cfg, batch)
+        dom = max(kern, key=lambda k: kern[k]["seconds"])
+        ach = kern[dom]["bytes"] / kern[dom]["seconds"] / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom)
+        line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                            "launch_us": round(kern[dom]["seconds"] * 1e6, 2),
+                            "all": {k: {"us": round(v["seconds"] * 1e6, 2),
+                                        "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in kern.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            del model, step, graph
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, args.cpu_steps)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

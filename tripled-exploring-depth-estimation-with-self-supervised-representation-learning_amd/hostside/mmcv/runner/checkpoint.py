@@ -1,0 +1,60 @@
+"""Checkpoint format of mmcv 0.4.4: {'meta': {...}, 'state_dict': CPU tensors without the
+'module.' prefix, 'optimizer': optimizer.state_dict()} saved as work_dir/epoch_N.pth."""
+import os
+import time
+from collections import OrderedDict
+
+import torch
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def load_state_dict(module, state_dict, strict=False, logger=None):
+    result = module.load_state_dict(state_dict, strict=strict)
+    problems = []
+    if result.unexpected_keys:
+        problems.append("unexpected key in source state_dict: {}".format(", ".join(result.unexpected_keys)))
+    if result.missing_keys:
+        problems.append("missing keys in source state_dict: {}".format(", ".join(result.missing_keys)))
+    if problems:
+        msg = "The model and loaded state dict do not match exactly\n" + "\n".join(problems)
+        if logger is not None:
+            logger.warning(msg)
+        else:
+            print(msg)
+
+
+def load_checkpoint(model, filename, map_location=None, strict=False, logger=None):
+    if not os.path.isfile(filename):
+        raise IOError("{} is not a checkpoint file".format(filename))
+    checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
+    if isinstance(checkpoint, OrderedDict):
+        state_dict = checkpoint
+    elif isinstance(checkpoint, dict) and "state_dict" in checkpoint:
+        state_dict = checkpoint["state_dict"]
+    else:
+        raise RuntimeError("No state_dict found in checkpoint file {}".format(filename))
+    if list(state_dict.keys()) and list(state_dict.keys())[0].startswith("module."):
+        state_dict = {k[7:]: v for k, v in state_dict.items()}
+    load_state_dict(_unwrap(model), state_dict, strict, logger)
+    return checkpoint
+
+
+def weights_to_cpu(state_dict):
+    out = OrderedDict()
+    for key, val in state_dict.items():
+        out[key] = val.cpu()
+    return out
+
+
+def save_checkpoint(model, filename, optimizer=None, meta=None):
+    meta = {} if meta is None else dict(meta)
+    from .. import __version__
+    meta.update(mmcv_version=__version__, time=time.asctime())
+    os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+    checkpoint = {"meta": meta, "state_dict": weights_to_cpu(_unwrap(model).state_dict())}
+    if optimizer is not None:
+        checkpoint["optimizer"] = optimizer.state_dict()
+    torch.save(checkpoint, filename)

@@ -1,0 +1,131 @@
+"""Training API (reference: mono/apis/trainer.py): train_mono, batch_processor, build_optimizer."""
+import re
+from collections import OrderedDict
+
+import torch
+from mmcv.parallel import MMDataParallel, MMDistributedDataParallel
+from mmcv.runner import DistSamplerSeedHook, Runner, obj_from_dict
+
+from mono.core import DistEvalMonoHook, DistOptimizerHook, NonDistEvalHook
+from mono.datasets import build_dataloader
+
+
+def _device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def change_input_variable(data):
+    """reference :19-29: every entry of the batch dict -> float32 on the training device.  The
+    copies are issued non-blocking (they are asynchronous when the loader pins memory)."""
+    dev = _device()
+    if isinstance(data, dict):
+        for k, v in data.items():
+            if "kp" not in k:
+                data[k] = torch.as_tensor(v).to(dev, dtype=torch.float32, non_blocking=True)
+    else:
+        data[0] = [torch.as_tensor(img).to(dev, dtype=torch.float32, non_blocking=True) for img in data[0]]
+    return data
+
+
+def batch_processor(model, data, train_mode):
+    """reference :32-60.  loss = sum of the means of every loss_dict entry.  The per-key values
+    are handed to the log buffer as device scalars (read back only when a log line is due)
+    instead of ~30 blocking .item() calls per iteration."""
+    if train_mode:
+        model.train()
+    data = change_input_variable(data)
+    model_out, losses = model(data)
+    log_vars = OrderedDict()
+    for name, value in losses.items():
+        if isinstance(value, torch.Tensor):
+            log_vars[name] = value.mean()
+        elif isinstance(value, list):
+            log_vars[name] = sum(v.mean() for v in value)
+        else:
+            raise TypeError("{} is not a tensor or list of tensors".format(name))
+    loss = sum(v for v in log_vars.values())
+    log_vars["loss"] = loss
+    detached = OrderedDict((str(k), v.detach()) for k, v in log_vars.items())
+    n = len(data[("color", 0, 0)]) if isinstance(data, dict) else len(data[0])
+    return dict(loss=loss, log_vars=detached, num_samples=n)
+
+
+def train_mono(model, dataset_train, dataset_val, cfg, distributed=False, validate=False):
+    if distributed:
+        _dist_train(model, dataset_train, dataset_val, cfg, validate=validate)
+    else:
+        _non_dist_train(model, dataset_train, dataset_val, cfg, validate=validate)
+
+
+def build_optimizer(model, optimizer_cfg):
+    """reference :77-144 (mmdet-style paramwise_options: bias_lr_mult, bias_decay_mult,
+    norm_decay_mult)."""
+    if hasattr(model, "module"):
+        model = model.module
+    optimizer_cfg = dict(optimizer_cfg)
+    paramwise = optimizer_cfg.pop("paramwise_options", None)
+    if paramwise is None:
+        return obj_from_dict(optimizer_cfg, torch.optim, dict(params=model.parameters()))
+    assert isinstance(paramwise, dict)
+    base_lr = optimizer_cfg["lr"]
+    base_wd = optimizer_cfg.get("weight_decay", None)
+    if "bias_decay_mult" in paramwise or "norm_decay_mult" in paramwise:
+        assert base_wd is not None
+    bias_lr_mult = paramwise.get("bias_lr_mult", 1.0)
+    bias_decay_mult = paramwise.get("bias_decay_mult", 1.0)
+    norm_decay_mult = paramwise.get("norm_decay_mult", 1.0)
+    groups = []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        group = {"params": [param]}
+        if re.search(r"(bn|gn)(\d+)?.(weight|bias)", name):
+            if base_wd is not None:
+                group["weight_decay"] = base_wd * norm_decay_mult
+        elif name.endswith(".bias"):
+            group["lr"] = base_lr * bias_lr_mult
+            if base_wd is not None:
+                group["weight_decay"] = base_wd * bias_decay_mult
+        groups.append(group)
+    return getattr(torch.optim, optimizer_cfg.pop("type"))(groups, **optimizer_cfg)
+
+
+def _finish_runner(runner, cfg, data_loaders):
+    if cfg.resume_from:
+        runner.resume(cfg.resume_from)
+    elif cfg.load_from:
+        runner.load_checkpoint(cfg.load_from)
+    runner.run(data_loaders, cfg.workflow, cfg.total_epochs)
+
+
+def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
+    data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, dist=True)]
+    if cfg.get("syncbn", False):
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    dev = _device()
+    model = MMDistributedDataParallel(model.to(dev), find_unused_parameters=cfg.get("find_unused_parameters", False),
+                                      device_ids=[dev.index] if dev.type == "cuda" else None,
+                                      broadcast_buffers=False)
+    optimizer = build_optimizer(model, cfg.optimizer)
+    runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
+    runner.register_training_hooks(cfg.lr_config, DistOptimizerHook(**cfg.optimizer_config),
+                                   cfg.checkpoint_config, cfg.log_config)
+    runner.register_hook(DistSamplerSeedHook())
+    if validate:
+        if "num_classes" in cfg:
+            raise NotImplementedError("segmentation evaluation is outside the depth training path")
+        runner.register_hook(DistEvalMonoHook(dataset_val, cfg.get("validate_interval", 1), cfg))
+    _finish_runner(runner, cfg, data_loaders)
+
+
+def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False):
+    data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, len(cfg.gpus), dist=False)]
+    model = MMDataParallel(model, device_ids=list(range(len(cfg.gpus)))).to(_device())
+    optimizer = build_optimizer(model, cfg.optimizer)
+    runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
+    runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.checkpoint_config, cfg.log_config)
+    if validate:
+        if "num_classes" in cfg:
+            raise NotImplementedError("segmentation evaluation is outside the depth training path")
+        runner.register_hook(NonDistEvalHook(dataset_val, cfg))
+    _finish_runner(runner, cfg, data_loaders)
