@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/tripled_hip.h
+declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "tripled_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(td_[a-z_A-Z0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(native.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libtripled_hip.so does not export %s" % n
+    assert set(names) == set(native.SIGNATURES), "ctypes binding and header disagree"
+
+
+def test_argument_validation_without_gpu():
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native
+    lib = native.load()
+    assert lib.td_abi_version() == 1
+    assert lib.td_photo_num_blocks(12, 192, 640) == 12 * 12 * 10
+    assert lib.td_photo_bwd_num_blocks(12, 192, 640) == 12 * 24 * 10
+    assert lib.td_smooth_num_blocks(12, 96, 320) == 12 * 6 * 5
+    # null pointers / bad sizes are rejected before any launch
+    assert lib.td_sum_scaled(None, 4, 1.0, None, None) == -1
+    assert lib.td_photo_identity(None, None, 2, 1, 8, 8, None, None) == -1
+    assert lib.td_smooth_finish(None, 1, 8, 8, 1.0, None, None) == -1
+    assert b"bad argument" in lib.td_error_string(-1)
+
+
+def test_product_fails_loudly_without_hip_device():
+    """No silent CPU fallback: CPU tensors are refused by the product loss backend."""
+    import torch
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native, ops
+    with pytest.raises(native.NativeLibraryError):
+        ops.photo_identity(torch.rand(1, 3, 8, 8), [torch.rand(1, 3, 8, 8)])
+    with pytest.raises(native.NativeLibraryError):
+        native.load("/nonexistent/libtripled_hip.so") if native._lib is None else (_ for _ in ()).throw(
+            native.NativeLibraryError("already loaded"))
