@@ -56,7 +56,8 @@ def parse():
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--syncbn", default="config", choices=["config", "on", "off"])
-    p.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    p.add_argument("--miopen-find", default="config", choices=["config", "on", "off"],
+                   help="torch.backends.cudnn.benchmark = MIOpen find mode; default: the config's cudnn_benchmark")
     return p.parse_args()
 
 
@@ -198,9 +199,9 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
-
     cfg = Config.fromfile(args.config)
+    torch.backends.cudnn.benchmark = {"config": bool(cfg.get("cudnn_benchmark", False)), "on": True,
+                                      "off": False}[args.miopen_find]
     m = cfg.model
     B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
     torch.manual_seed(1024)

@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Stand-alone timing of the hand-written loss kernels at the BASELINE size (B=12, 192x640),
+through the C ABI.  Used under rocprofv3 (--kernel-trace / --pmc) and on its own.
+
+  python tools/kernel_bench.py [--iters 20] [--B 12 --H 192 --W 640] [--only fwd,bwd]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import tripled_amd  # noqa: F401,E402
+from tripled_amd import native  # noqa: E402
+from mono.datasets.synthetic import synthetic_batch  # noqa: E402
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--B", type=int, default=12)
+    ap.add_argument("--H", type=int, default=192)
+    ap.add_argument("--W", type=int, default=640)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--adversarial", action="store_true", help="i.i.d. random frames and large random poses")
+    args = ap.parse_args()
+    only = set(args.only.split(",")) if args.only else None
+    lib = native.load()
+    dev = torch.device("cuda", 0)
+    B, H, W = args.B, args.H, args.W
+    batch = synthetic_batch(B, H, W, seed=1000, device=dev)
+    tgt = batch[("color", 0, 0)].contiguous()
+    srcs = [batch[("color", -1, 0)].contiguous(), batch[("color", 1, 0)].contiguous()]
+    if args.adversarial:
+        tgt = torch.rand_like(tgt)
+        srcs = [torch.rand_like(s) for s in srcs]
+    n_src = 2
+    invK = batch["inv_K"].contiguous()
+    g = torch.Generator().manual_seed(5)
+    Ts = []
+    for _ in range(n_src):
+        T = torch.eye(4).repeat(B, 1, 1)
+        T[:, :3, 3] = (0.5 if args.adversarial else 0.05) * torch.randn(B, 3, generator=g)
+        Ts.append(T)
+    P = torch.stack([torch.matmul(batch["K"].cpu(), T)[:, :3, :] for T in Ts], 0).contiguous().to(dev)
+    idloss = torch.empty(B, n_src, H, W, device=dev)
+    noise = torch.randn(n_src, B, H, W, device=dev)
+    argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+    part = torch.empty(lib.td_photo_num_blocks(B, H, W), device=dev)
+    d_up = torch.empty(B, H, W, device=dev)
+    dpp = torch.empty(lib.td_photo_bwd_num_blocks(B, H, W), n_src * 12, device=dev)
+    dP = torch.empty(n_src, B, 3, 4, device=dev)
+    gs = torch.ones(1, device=dev)
+    loss = torch.empty(1, device=dev)
+    st = native.stream()
+    sp = native.ptr_array(srcs)
+    px = B * H * W
+    res = {}
+
+    def want(k):
+        return only is None or k in only
+
+    if want("identity"):
+        res["identity"] = timeit(lambda: native.check(lib.td_photo_identity(
+            native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "id"), args.iters)
+    else:
+        native.check(lib.td_photo_identity(native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "id")
+    for s in range(4):
+        hs, ws = H >> (s + 1), W >> (s + 1)
+        disp = (0.1 + 0.8 * torch.rand(B, 1, hs, ws, device=dev)).contiguous()
+        d_disp = torch.empty_like(disp)
+        img = torch.rand(B, 3, hs, ws, device=dev)
+        mean = torch.empty(B, device=dev)
+        nsb = lib.td_smooth_num_blocks(B, hs, ws)
+        sp6 = torch.empty(nsb, 6, device=dev)
+        ghat = torch.empty(B, hs, ws, device=dev)
+        dotp = torch.empty(nsb, device=dev)
+
+        def fwd():
+            native.check(lib.td_photo_fwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+                                          native.ptr(idloss), native.ptr(noise), B, H, W, hs, ws, 0.1, 100.0,
+                                          native.ptr(argmin), None, None, native.ptr(part), st), "fwd")
+
+        def bwd():
+            native.check(lib.td_photo_bwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+                                          native.ptr(argmin), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
+                                          0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
+
+        def adj():
+            native.check(lib.td_upsample_adjoint(native.ptr(d_up), B, H, W, hs, ws, native.ptr(d_disp), 0, st), "adj")
+
+        def red():
+            native.check(lib.td_reduce_dP(native.ptr(dpp), n_src, B, H, W, native.ptr(dP), st), "red")
+            native.check(lib.td_sum_scaled(native.ptr(part), part.numel(), 1.0, native.ptr(loss), st), "sum")
+
+        def smf():
+            native.check(lib.td_smooth_fwd(native.ptr(disp), native.ptr(img), B, hs, ws, 1, native.ptr(mean),
+                                           native.ptr(sp6), st), "smf")
+            native.check(lib.td_smooth_finish(native.ptr(sp6), B, hs, ws, 1e-3, native.ptr(loss), st), "smfin")
+
+        def smb():
+            native.check(lib.td_smooth_bwd(native.ptr(disp), native.ptr(img), native.ptr(mean), B, hs, ws, 1,
+                                           native.ptr(gs), 1e-3, native.ptr(ghat), native.ptr(dotp),
+                                           native.ptr(d_disp), 0, st), "smb")
+
+        fwd()
+        for name, fn in (("fwd", fwd), ("bwd", bwd), ("adjoint", adj), ("reduce", red), ("smooth_fwd", smf),
+                         ("smooth_bwd", smb)):
+            if want(name):
+                res["%s_s%d" % (name, s)] = timeit(fn, args.iters)
+    f0 = (12 + 24 + 1 + 0.25) * px
+    out = {"us": {k: round(v, 2) for k, v in res.items()}}
+    if "fwd_s0" in res:
+        out["fwd_s0_GBps"] = round(f0 / res["fwd_s0"] / 1e3, 1)
+    if "bwd_s0" in res:
+        out["bwd_s0_GBps"] = round((f0 + 0.25 * px) / res["bwd_s0"] / 1e3, 1)
+    out["sum_us"] = round(sum(res.values()), 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@
 // TILE_W = 64 puts one image row segment on one wave: global reads of a row are a single
 // 256-byte coalesced request and LDS rows are read conflict-free (consecutive banks).
 #define TD_THREADS 256
+#define TD_FWD_THREADS 512
 #define TD_TILE_W 64
 #define TD_FWD_TILE_H 16
 #define TD_BWD_TILE_H 8
@@ -40,14 +41,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Sum over the 256-thread block; result valid in thread 0. `scratch` >= 4 floats of LDS.
+// Sum over a block of NW waves; result valid in thread 0. `scratch` >= NW floats of LDS.
+// Fixed association order -> bit-reproducible.
+template <int NW = 4>
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) scratch[wid] = v;
   __syncthreads();
   float r = 0.f;
-  if (threadIdx.x == 0) r = ((scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NW; i += 2) r += scratch[i] + scratch[i + 1];
+  }
   __syncthreads();
   return r;
 }
@@ -91,10 +97,9 @@ __device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int 
                                                float ry, float rx, int qy, int qx) {
   const UpIdx vy = up_index(qy, ry, hs);
   const UpIdx vx = up_index(qx, rx, ws);
-  const float* r0 = d + (size_t)vy.i0 * ws;
-  const float* r1 = d + (size_t)vy.i1 * ws;
-  return vy.l0 * (vx.l0 * r0[vx.i0] + vx.l1 * r0[vx.i1]) +
-         vy.l1 * (vx.l0 * r1[vx.i0] + vx.l1 * r1[vx.i1]);
+  const int o0 = vy.i0 * ws, o1 = vy.i1 * ws;
+  return vy.l0 * (vx.l0 * d[o0 + vx.i0] + vx.l1 * d[o0 + vx.i1]) +
+         vy.l1 * (vx.l0 * d[o1 + vx.i0] + vx.l1 * d[o1 + vx.i1]);
 }
 
 // Depth -> camera point -> source pixel -> bilinear taps.  Mirrors the reference's fp32
@@ -113,7 +118,10 @@ __device__ __forceinline__ Tap project_tap(const float* ik, const float* P, floa
   const float c2 = P[8] * X + P[9] * Y + P[10] * Z + P[11];
   const float z = c2 + 1e-7f;
   cz[0] = c0; cz[1] = c1; cz[2] = z;
-  const float u = c0 / z, v = c1 / z;
+  // one correctly-rounded reciprocal per (pixel, source); u = c0 * (1/z) differs from the
+  // reference's c0 / z by <= 1 ulp (6e-8 relative: 4e-5 px at x = 640)
+  const float iz = 1.f / z;
+  const float u = c0 * iz, v = c1 * iz;
   const float gx = (u / (float)(W - 1) - 0.5f) * 2.f;
   const float gy = (v / (float)(H - 1) - 0.5f) * 2.f;
   float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
@@ -140,15 +148,44 @@ __device__ __forceinline__ Tap project_tap(const float* ik, const float* P, floa
   return t;
 }
 
-__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, int W, const Tap& t) {
-  const float* r0 = plane + (size_t)t.y0 * W;
-  const float* r1 = plane + (size_t)t.y1 * W;
-  float o = r0[t.x0] * t.nw;
-  if (t.in_e) o += r0[t.x1] * t.ne;
-  if (t.in_s) o += r1[t.x0] * t.sw;
-  if (t.in_e && t.in_s) o += r1[t.x1] * t.se;
+// The four taps of one channel plane.  All four loads are issued unconditionally (the tap
+// coordinates are clamped, so the addresses are always valid) -- predicated loads make the
+// compiler serialise every gather behind its own s_waitcnt.
+struct TapVals {
+  float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ TapVals load_taps(const float* __restrict__ plane, int W, const Tap& t) {
+  // 32-bit element offsets against a wave-uniform base (saddr form of global_load)
+  const int o0 = t.y0 * W, o1 = t.y1 * W;
+  TapVals v;
+  v.nw = plane[o0 + t.x0];
+  v.ne = plane[o0 + t.x1];
+  v.sw = plane[o1 + t.x0];
+  v.se = plane[o1 + t.x1];
+  return v;
+}
+
+// ATen accumulation order nw, ne, sw, se.  A tap outside the image has a clamped address and
+// an exactly-zero weight (the clipped coordinate sits on the last row/column), so adding
+// value*0 equals ATen's skipping of that tap for finite images.
+__device__ __forceinline__ float blend_taps(const TapVals& v, const Tap& t) {
+  float o = v.nw * t.nw;
+  o += v.ne * t.ne;
+  o += v.sw * t.sw;
+  o += v.se * t.se;
   return o;
 }
+
+__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, int W, const Tap& t) {
+  return blend_taps(load_taps(plane, W, t), t);
+}
+
+// 1/x and sqrt(x) to ~1 ulp (v_rcp_f32 / v_sqrt_f32) for quantities whose conditioning does not
+// need correctly rounded results (SSIM ratio, channel means, robust-L1); sampling coordinates
+// keep IEEE division.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // SSIM loss value for one channel from 3x3 window sums (sum of x, y, x^2, y^2, xy).
 __device__ __forceinline__ float ssim_from_sums(float sx, float sy, float sxx, float syy, float sxy) {
@@ -159,7 +196,7 @@ __device__ __forceinline__ float ssim_from_sums(float sx, float sy, float sxx, f
   const float cxy = sxy * k - mx * my;
   const float n = (2.f * mx * my + TD_SSIM_C1) * (2.f * cxy + TD_SSIM_C2);
   const float d = (mx * mx + my * my + TD_SSIM_C1) * (vx + vy + TD_SSIM_C2);
-  const float s = (1.f - n / d) / 2.f;
+  const float s = (1.f - n * fast_rcp(d)) * 0.5f;
   return fminf(fmaxf(s, 0.f), 1.f);
 }
 

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(TD_THREADS) void photo_bwd_kernel(const PhotoBwdArg
   const int ox = tid & 63, oyb = (tid >> 6) * 2;
   float dup[2] = {0.f, 0.f};
 
+#pragma unroll 1
   for (int f = 0; f < NS; ++f) {
     __syncthreads();   // previous frame's s_x / s_cf fully consumed; s_cam / s_y visible
     const float* Pf = s_cam + 9 + f * 12;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(TD_THREADS) void photo_bwd_kernel(const PhotoBwdArg
       const int py = pos / B2W, px = pos - py * B2W;
       const int qy = reflect1(ty0 + py - 2, H), qx = reflect1(tx0 + px - 2, W);
       const float d = upsample_disp(dispb, a.hs, a.ws, ry, rx, qy, qx);
-      const float depth = 1.f / (a.min_disp + a.disp_range * d);
+      const float depth = fast_rcp(a.min_disp + a.disp_range * d);
       float pt[3], cz[3];
       const Tap t = project_tap(s_cam, Pf, depth, qx, qy, W, H, pt, cz);
 #pragma unroll
@@ -116,9 +117,10 @@ __global__ __launch_bounds__(TD_THREADS) void photo_bwd_kernel(const PhotoBwdArg
           const float A1 = 2.f * mx * my + TD_SSIM_C1, A2 = 2.f * cxy + TD_SSIM_C2;
           const float B1 = mx * mx + my * my + TD_SSIM_C1, B2 = vx + vy + TD_SSIM_C2;
           const float n = A1 * A2, d = B1 * B2;
-          const float s = (1.f - n / d) / 2.f;
+          const float invd = fast_rcp(d);
+          const float s = (1.f - n * invd) * 0.5f;
           if (s >= 0.f && s <= 1.f) {     // clamp passes gradient on the closed interval
-            const float invd = 1.f / d, q = n * invd;
+            const float q = n * invd;
             al = -invd * (my * (A2 - A1) - q * mx * (B2 - B1)) * g_ssim;
             be = invd * q * B1 * g_ssim;
             ga = -invd * A1 * g_ssim;
@@ -163,14 +165,14 @@ __global__ __launch_bounds__(TD_THREADS) void photo_bwd_kernel(const PhotoBwdArg
           float v = Ga + Gb * x + Gc * y;
           if (mine) {
             const float df = x - y;
-            v += g_l1 * df / sqrtf(df * df + TD_L1_EPS2);
+            v += g_l1 * df * fast_rcp(fast_sqrt(df * df + TD_L1_EPS2));
           }
           gw[c] = v;
           any = any || (v != 0.f);
         }
         if (any) {
           const float d = upsample_disp(dispb, a.hs, a.ws, ry, rx, gy, gx);
-          const float depth = 1.f / (a.min_disp + a.disp_range * d);
+          const float depth = fast_rcp(a.min_disp + a.disp_range * d);
           float pt[3], cz[3];
           const Tap t = project_tap(s_cam, Pf, depth, gx, gy, W, H, pt, cz);
           float gix = 0.f, giy = 0.f;
@@ -180,17 +182,18 @@ __global__ __launch_bounds__(TD_THREADS) void photo_bwd_kernel(const PhotoBwdArg
           for (int c = 0; c < 3; ++c) {
             const float* r0 = srcb + (size_t)c * plane + (size_t)t.y0 * W;
             const float* r1 = srcb + (size_t)c * plane + (size_t)t.y1 * W;
-            const float vnw = r0[t.x0];
-            const float vne = t.in_e ? r0[t.x1] : 0.f;
-            const float vsw = t.in_s ? r1[t.x0] : 0.f;
-            const float vse = (t.in_e && t.in_s) ? r1[t.x1] : 0.f;
+            const float l_nw = r0[t.x0], l_ne = r0[t.x1], l_sw = r1[t.x0], l_se = r1[t.x1];
+            const float vnw = l_nw;
+            const float vne = t.in_e ? l_ne : 0.f;
+            const float vsw = t.in_s ? l_sw : 0.f;
+            const float vse = (t.in_e && t.in_s) ? l_se : 0.f;
             gix += gw[c] * (-vnw * ey + vne * ey - vsw * wy + vse * wy);
             giy += gw[c] * (-vnw * ex - vne * wx + vsw * ex + vse * wx);
           }
           // grid_sampler unnormalise (W/2) * clip multiplier, then (u/(W-1) - 0.5) * 2
           const float du = gix * t.gmx * ((float)W * 0.5f) * 2.f / (float)(W - 1);
           const float dv = giy * t.gmy * ((float)H * 0.5f) * 2.f / (float)(H - 1);
-          const float iz = 1.f / cz[2];
+          const float iz = fast_rcp(cz[2]);
           const float dc0 = du * iz, dc1 = dv * iz;
           const float dc2 = -(du * cz[0] + dv * cz[1]) * iz * iz;
           dP[0] += dc0 * pt[0]; dP[1] += dc0 * pt[1]; dP[2] += dc0 * pt[2]; dP[3] += dc0;

@@ -70,20 +70,28 @@ __global__ __launch_bounds__(TD_THREADS) void photo_fwd_kernel(const PhotoFwdArg
         for (int c = 0; c < 3; ++c) s_x[f][c][py][px] = a.src[f][((size_t)b * 3 + c) * plane + off];
     } else {
       const float d = upsample_disp(dispb, a.hs, a.ws, ry, rx, qy, qx);
-      const float depth = 1.f / (a.min_disp + a.disp_range * d);
+      const float depth = fast_rcp(a.min_disp + a.disp_range * d);
       const bool own = a.warped != nullptr && py >= 1 && py <= FT_H && px >= 1 && px <= FT_W &&
                        (ty0 + py - 1) < H && (tx0 + px - 1) < W;
+      Tap taps[NS];
 #pragma unroll
       for (int f = 0; f < NS; ++f) {
         float pt[3], cz[3];
-        const Tap t = project_tap(s_cam, s_cam + 9 + f * 12, depth, qx, qy, W, H, pt, cz);
+        taps[f] = project_tap(s_cam, s_cam + 9 + f * 12, depth, qx, qy, W, H, pt, cz);
+      }
+      TapVals tv[NS][3];
+#pragma unroll
+      for (int f = 0; f < NS; ++f)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tv[f][c] = load_taps(a.src[f] + ((size_t)b * 3 + c) * plane, W, taps[f]);
+#pragma unroll
+      for (int f = 0; f < NS; ++f)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float v = sample_tap(a.src[f] + ((size_t)b * 3 + c) * plane, W, t);
+          const float v = blend_taps(tv[f][c], taps[f]);
           s_x[f][c][py][px] = v;
           if (own) a.warped[(((size_t)f * a.B + b) * 3 + c) * plane + off] = v;
         }
-      }
     }
   }
   __syncthreads();
@@ -131,9 +139,9 @@ __global__ __launch_bounds__(TD_THREADS) void photo_fwd_kernel(const PhotoFwdArg
           const float sxy = hxy[0][f][c] + hxy[1][f][c] + hxy[2][f][c];
           ss += ssim_from_sums(sx, sy, sxx, syy, sxy);
           const float df = cy[pc][c] - cxv[pc][f][c];
-          l1 += sqrtf(df * df + TD_L1_EPS2);
+          l1 += fast_sqrt(df * df + TD_L1_EPS2);
         }
-        loss[f] = 0.85f * (ss / 3.f) + 0.15f * (l1 / 3.f);
+        loss[f] = 0.85f * (ss * (1.f / 3.f)) + 0.15f * (l1 * (1.f / 3.f));
       }
       if (gy < H && gx < W) {
         const size_t pix = (size_t)gy * W + gx;
@@ -236,7 +244,7 @@ extern "C" int td_photo_fwd(const float* tgt, const float* const* src, int n_src
   if (n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W) return TD_ERR_BAD_ARG;
   if (!(min_depth > 0.f) || !(max_depth > min_depth)) return TD_ERR_BAD_ARG;
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
-  if (H < 3 || W < 3) return TD_ERR_UNSUPPORTED;
+  if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   return dispatch_fwd(tgt, src, n_src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth,
                       max_depth, argmin, warped, min_map, partial, nullptr, false, stream);
 }
