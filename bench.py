@@ -130,7 +130,7 @@ def roofline_of_hot_kernels(cfg, batch):
     invK = batch["inv_K"].contiguous()
     g = torch.Generator(device="cpu").manual_seed(5)
     T = torch.eye(4).repeat(B, 1, 1)
-    T[:, :3, 3] = 0.05 * torch.randn(B, 3, generator=g)
+    T[:, :3, 3] = 0.004 * torch.randn(B, 3, generator=g)      # a few pixels of parallax, like real ego-motion
     P = torch.stack([torch.matmul(batch["K"].cpu(), T)[:, :3, :]] * n_src, 0).contiguous().to(dev)
     idloss = torch.empty(B, n_src, H, W, device=dev)
     noise = torch.randn(n_src, B, H, W, device=dev)
@@ -146,7 +146,9 @@ def roofline_of_hot_kernels(cfg, batch):
     px = B * H * W
     for s in (0,):
         hs, ws = H >> (s + 1), W >> (s + 1)
-        disp = (0.1 + 0.8 * torch.rand(B, 1, hs, ws, device=dev)).contiguous()
+        low = torch.rand(B, 1, hs // 8, ws // 8, device=dev)
+        disp = (0.3 + 0.4 * torch.nn.functional.interpolate(low, size=(hs, ws), mode="bilinear",
+                                                            align_corners=False)).contiguous()
 
         def fwd():
             native.check(lib.td_photo_fwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),

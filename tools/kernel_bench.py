@@ -55,7 +55,8 @@ def main():
     Ts = []
     for _ in range(n_src):
         T = torch.eye(4).repeat(B, 1, 1)
-        T[:, :3, 3] = (0.5 if args.adversarial else 0.05) * torch.randn(B, 3, generator=g)
+        # realistic ego-motion: a few pixels of parallax at the depths below; adversarial: ~100 px
+        T[:, :3, 3] = (0.5 if args.adversarial else 0.004) * torch.randn(B, 3, generator=g)
         Ts.append(T)
     P = torch.stack([torch.matmul(batch["K"].cpu(), T)[:, :3, :] for T in Ts], 0).contiguous().to(dev)
     idloss = torch.empty(B, n_src, H, W, device=dev)
@@ -82,7 +83,12 @@ def main():
         native.check(lib.td_photo_identity(native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "id")
     for s in range(4):
         hs, ws = H >> (s + 1), W >> (s + 1)
-        disp = (0.1 + 0.8 * torch.rand(B, 1, hs, ws, device=dev)).contiguous()
+        if args.adversarial:
+            disp = (0.1 + 0.8 * torch.rand(B, 1, hs, ws, device=dev)).contiguous()
+        else:   # spatially smooth disparity, like a decoder output
+            low = torch.rand(B, 1, max(hs // 8, 2), max(ws // 8, 2), device=dev)
+            disp = (0.3 + 0.4 * torch.nn.functional.interpolate(low, size=(hs, ws), mode="bilinear",
+                                                                align_corners=False)).contiguous()
         d_disp = torch.empty_like(disp)
         img = torch.rand(B, 3, hs, ws, device=dev)
         mean = torch.empty(B, device=dev)

@@ -102,15 +102,12 @@ __device__ __forceinline__ float upsample_disp(const float* __restrict__ d, int 
          vy.l1 * (vx.l0 * d[o1 + vx.i0] + vx.l1 * d[o1 + vx.i1]);
 }
 
-// Depth -> camera point -> source pixel -> bilinear taps.  Mirrors the reference's fp32
-// operation sequence (Backproject/Project in layers.py, grid_sampler in ATen) step by step.
-__device__ __forceinline__ Tap project_tap(const float* ik, const float* P, float depth,
-                                           int qx, int qy, int W, int H,
-                                           float* pt /*3: camera point*/, float* cz /*c0,c1,z*/) {
-  const float fx = (float)qx, fy = (float)qy;
-  const float r0 = ik[0] * fx + ik[1] * fy + ik[2];
-  const float r1 = ik[3] * fx + ik[4] * fy + ik[5];
-  const float r2 = ik[6] * fx + ik[7] * fy + ik[8];
+// Camera ray (inv_K . (x,y,1)) scaled by depth -> camera point -> source pixel -> bilinear taps.
+// Mirrors the reference's fp32 operation sequence (Backproject/Project in layers.py,
+// grid_sampler in ATen) step by step.
+__device__ __forceinline__ Tap project_ray(float r0, float r1, float r2, const float* P, float depth,
+                                           int W, int H, float* pt /*3: camera point*/,
+                                           float* cz /*c0,c1,z*/) {
   const float X = depth * r0, Y = depth * r1, Z = depth * r2;
   pt[0] = X; pt[1] = Y; pt[2] = Z;
   const float c0 = P[0] * X + P[1] * Y + P[2] * Z + P[3];
@@ -122,8 +119,8 @@ __device__ __forceinline__ Tap project_tap(const float* ik, const float* P, floa
   // reference's c0 / z by <= 1 ulp (6e-8 relative: 4e-5 px at x = 640)
   const float iz = 1.f / z;
   const float u = c0 * iz, v = c1 * iz;
-  const float gx = (u / (float)(W - 1) - 0.5f) * 2.f;
-  const float gy = (v / (float)(H - 1) - 0.5f) * 2.f;
+  const float gx = (u * (1.f / (float)(W - 1)) - 0.5f) * 2.f;   // reciprocal hoisted by the compiler
+  const float gy = (v * (1.f / (float)(H - 1)) - 0.5f) * 2.f;   // (<= 1 ulp vs the reference's division)
   float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
   float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
   Tap t;
@@ -148,6 +145,15 @@ __device__ __forceinline__ Tap project_tap(const float* ik, const float* P, floa
   return t;
 }
 
+__device__ __forceinline__ Tap project_tap(const float* ik, const float* P, float depth,
+                                           int qx, int qy, int W, int H, float* pt, float* cz) {
+  const float fx = (float)qx, fy = (float)qy;
+  const float r0 = ik[0] * fx + ik[1] * fy + ik[2];
+  const float r1 = ik[3] * fx + ik[4] * fy + ik[5];
+  const float r2 = ik[6] * fx + ik[7] * fy + ik[8];
+  return project_ray(r0, r1, r2, P, depth, W, H, pt, cz);
+}
+
 // The four taps of one channel plane.  All four loads are issued unconditionally (the tap
 // coordinates are clamped, so the addresses are always valid) -- predicated loads make the
 // compiler serialise every gather behind its own s_waitcnt.
@@ -157,12 +163,12 @@ struct TapVals {
 
 __device__ __forceinline__ TapVals load_taps(const float* __restrict__ plane, int W, const Tap& t) {
   // 32-bit element offsets against a wave-uniform base (saddr form of global_load)
-  const int o0 = t.y0 * W, o1 = t.y1 * W;
+  const unsigned o0 = (unsigned)(t.y0 * W), o1 = (unsigned)(t.y1 * W);
   TapVals v;
-  v.nw = plane[o0 + t.x0];
-  v.ne = plane[o0 + t.x1];
-  v.sw = plane[o1 + t.x0];
-  v.se = plane[o1 + t.x1];
+  v.nw = plane[o0 + (unsigned)t.x0];
+  v.ne = plane[o0 + (unsigned)t.x1];
+  v.sw = plane[o1 + (unsigned)t.x0];
+  v.se = plane[o1 + (unsigned)t.x1];
   return v;
 }
 

@@ -1,16 +1,21 @@
 // Fused photometric forward: upsample(disp) -> depth -> back-project -> project -> bilinear
 // gather -> 3x3 reflect-padded SSIM + robust L1 -> per-pixel min over {identity, warped}.
-// One 256-thread workgroup per 16x64 tile; the warped sources and the target are staged in
-// LDS with a 1-pixel halo, each wave then slides a 3-row window down its 4x64 strip so every
-// horizontal 3-sum is formed once and reused by the three vertical windows that contain it.
+//
+// Streaming formulation, no LDS and no barriers: one wave owns a strip of 62 output columns
+// (lanes 1..62; lanes 0 and 63 carry the left/right halo column) and marches down R output
+// rows.  Horizontal 3-sums of the SSIM window come from the neighbouring lanes (DPP wave
+// shifts), vertical 3-sums from a two-row register ring.  The row loop is software-pipelined
+// two rows deep: while row r is reduced, the gathers of row r+1 and the low-res disparity
+// taps of row r+2 are in flight, so a wave keeps ~30 loads outstanding without relying on
+// occupancy.  Blocks are remapped so that consecutive tasks (neighbouring strips / row chunks
+// that share halo lines) land on the same XCD and hit its L2.
 #include "td_common.h"
 
 namespace td {
 
-constexpr int FT_H = TD_FWD_TILE_H;
-constexpr int FT_W = TD_TILE_W;
-constexpr int FH = FT_H + 2;   // halo rows
-constexpr int FW = FT_W + 2;   // halo cols
+constexpr int FS_ROWS = 8;        // output rows per wave task
+constexpr int FS_COLS = 62;       // output columns per wave task
+constexpr int FS_WAVES = 4;       // independent wave tasks per 256-thread block
 
 template <int NS>
 struct PhotoFwdArgs {
@@ -27,163 +32,288 @@ struct PhotoFwdArgs {
   float* partial;
   float* idloss_out;   // identity mode only
   int B, H, W, hs, ws;
+  int nstrips, nchunks, ntasks, blocks_per_xcd;
   float min_disp, disp_range;
 };
 
-// IDENT = true: "pred" is the raw source frame (auto-mask term); writes idloss_out.
-template <int NS, bool IDENT>
-__global__ __launch_bounds__(TD_THREADS) void photo_fwd_kernel(const PhotoFwdArgs<NS> a) {
-  __shared__ float s_y[3][FH][FW];
-  __shared__ float s_x[NS][3][FH][FW];
-  __shared__ float s_cam[9 + NS * 12];
-  __shared__ float s_red[4];
+// value of the lane to the left / right (wave-wide shift by one lane; the edge lanes receive 0 --
+// they only ever feed halo columns whose results are discarded).  old = 0 + bound_ctrl lets the
+// compiler fold the shift into the consuming v_add_f32 (v_add_f32_dpp).
+__device__ __forceinline__ float lane_left(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */,
+                                                               0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */,
+                                                               0xf, 0xf, true));
+}
+__device__ __forceinline__ float hsum3(float v) { return (lane_left(v) + v) + lane_right(v); }
 
-  const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int ty0 = blockIdx.y * FT_H, tx0 = blockIdx.x * FT_W;
+// per-row vertical source rows of the bilinear up-sampling (wave-uniform)
+struct UpRow {
+  int o0, o1;       // element offsets of the two low-res rows
+  float l0, l1;
+};
+
+// Everything one pipeline row needs, requested one iteration ahead of its use.
+template <int NS>
+struct RowLoads {
+  Tap taps[NS];
+  TapVals tv[NS][3];
+  float yv[3];
+  float xv[NS][3];     // identity mode: raw source pixels
+  float idv[NS];       // auto-mask term of the output row this pipeline row completes
+  float nz[NS];
+};
+
+struct DispTaps {
+  float v[4];
+  UpRow ur;
+};
+
+// MODE: 0 = identity-term kernel, 1 = warped terms only, 2 = + auto-mask, 3 = + auto-mask noise.
+// KEEP: also write the warped sources.
+template <int NS, int MODE, bool KEEP>
+__global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwdArgs<NS> a) {
+  constexpr bool IDENT = MODE == 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // XCD-aware remap: hardware deals consecutive blocks round-robin over the 8 XCDs; give every
+  // XCD a contiguous range of tasks instead (speed only, any placement is correct)
+  const int bid = (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3);
+  const int task = bid * FS_WAVES + wave;
+  if (task >= a.ntasks) return;
+  const int strip = task % a.nstrips;
+  const int chunk = (task / a.nstrips) % a.nchunks;
+  const int b = task / (a.nstrips * a.nchunks);
+
   const int H = a.H, W = a.W;
-  const size_t plane = (size_t)H * W;
+  const unsigned plane = (unsigned)(H * W);
+  const int x = strip * FS_COLS - 1 + lane;          // padded-domain column of this lane
+  const int qx = reflect1(x, W);
+  const int y0 = chunk * FS_ROWS;
+  const bool col_out = lane >= 1 && lane <= FS_COLS && x < W;
+  const int xo = x < W ? (x < 0 ? 0 : x) : W - 1;    // clamped column for prefetching per-pixel inputs
 
+  const float* tgtb = a.tgt + (size_t)b * 3 * plane;
+  const float* srcb[NS];
+#pragma unroll
+  for (int f = 0; f < NS; ++f) srcb[f] = a.src[f] + (size_t)b * 3 * plane;
+
+  // ---- per-wave constants: camera, per-lane horizontal up-sampling taps, x part of the rays ----
+  float ik[9], P[NS][12];
+  UpIdx ux;
+  ux.i0 = ux.i1 = 0; ux.l0 = ux.l1 = 0.f;
+  float rx0 = 0.f, rx1 = 0.f, rx2 = 0.f;
+  const float* dispb = nullptr;
+  float ratio_y = 0.f;
   if (!IDENT) {
-    if (tid < 9) s_cam[tid] = a.invK[(size_t)b * 16 + (tid / 3) * 4 + (tid % 3)];
-    if (tid >= 64 && tid < 64 + NS * 12) {
-      const int k = tid - 64, f = k / 12, e = k % 12;
-      s_cam[9 + k] = a.P[((size_t)f * a.B + b) * 12 + e];
-    }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ik[i] = a.invK[b * 16 + (i / 3) * 4 + (i % 3)];
+#pragma unroll
+    for (int f = 0; f < NS; ++f)
+#pragma unroll
+      for (int e = 0; e < 12; ++e) P[f][e] = a.P[(f * a.B + b) * 12 + e];
+    ux = up_index(qx, (float)a.ws / (float)W, a.ws);
+    ratio_y = (float)a.hs / (float)H;
+    const float fx = (float)qx;
+    rx0 = ik[0] * fx; rx1 = ik[3] * fx; rx2 = ik[6] * fx;
+    dispb = a.disp + (size_t)b * a.hs * a.ws;
   }
 
-  const float ry = (float)a.hs / (float)H, rx = (float)a.ws / (float)W;
-  const float* dispb = IDENT ? nullptr : a.disp + (size_t)b * a.hs * a.ws;
-
-  // ---- phase 1: stage target + predictions for the haloed tile ----
-  for (int pos = tid; pos < FH * FW; pos += TD_THREADS) {
-    const int py = pos / FW, px = pos - py * FW;
-    const int qy = reflect1(ty0 + py - 1, H), qx = reflect1(tx0 + px - 1, W);
-    const size_t off = (size_t)qy * W + qx;
+  auto stage_a = [&](int k, DispTaps& d) {           // issue the 4 disparity loads of pipeline row k
+    const int qy = reflect1(y0 - 1 + k, H);
+    const UpIdx uy = up_index(qy, ratio_y, a.hs);
+    d.ur.o0 = uy.i0 * a.ws; d.ur.o1 = uy.i1 * a.ws; d.ur.l0 = uy.l0; d.ur.l1 = uy.l1;
+    d.v[0] = dispb[(unsigned)(d.ur.o0 + ux.i0)]; d.v[1] = dispb[(unsigned)(d.ur.o0 + ux.i1)];
+    d.v[2] = dispb[(unsigned)(d.ur.o1 + ux.i0)]; d.v[3] = dispb[(unsigned)(d.ur.o1 + ux.i1)];
+  };
+  auto stage_b = [&](int k, const DispTaps& d, RowLoads<NS>& L) {   // taps + gathers of pipeline row k
+    const int qy = reflect1(y0 - 1 + k, H);
+    const unsigned off = (unsigned)(qy * W + qx);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s_y[c][py][px] = a.tgt[((size_t)b * 3 + c) * plane + off];
+    for (int c = 0; c < 3; ++c) L.yv[c] = tgtb[c * plane + off];
     if (IDENT) {
 #pragma unroll
       for (int f = 0; f < NS; ++f)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_x[f][c][py][px] = a.src[f][((size_t)b * 3 + c) * plane + off];
+        for (int c = 0; c < 3; ++c) L.xv[f][c] = srcb[f][c * plane + off];
     } else {
-      const float d = upsample_disp(dispb, a.hs, a.ws, ry, rx, qy, qx);
-      const float depth = fast_rcp(a.min_disp + a.disp_range * d);
-      const bool own = a.warped != nullptr && py >= 1 && py <= FT_H && px >= 1 && px <= FT_W &&
-                       (ty0 + py - 1) < H && (tx0 + px - 1) < W;
-      Tap taps[NS];
+      const float dd = d.ur.l0 * (ux.l0 * d.v[0] + ux.l1 * d.v[1]) + d.ur.l1 * (ux.l0 * d.v[2] + ux.l1 * d.v[3]);
+      const float depth = fast_rcp(a.min_disp + a.disp_range * dd);
+      const float fy = (float)qy;
+      const float r0 = rx0 + ik[1] * fy + ik[2];
+      const float r1 = rx1 + ik[4] * fy + ik[5];
+      const float r2 = rx2 + ik[7] * fy + ik[8];
 #pragma unroll
       for (int f = 0; f < NS; ++f) {
         float pt[3], cz[3];
-        taps[f] = project_tap(s_cam, s_cam + 9 + f * 12, depth, qx, qy, W, H, pt, cz);
+        L.taps[f] = project_ray(r0, r1, r2, P[f], depth, W, H, pt, cz);
       }
-      TapVals tv[NS][3];
 #pragma unroll
       for (int f = 0; f < NS; ++f)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tv[f][c] = load_taps(a.src[f] + ((size_t)b * 3 + c) * plane, W, taps[f]);
+        for (int c = 0; c < 3; ++c) L.tv[f][c] = load_taps(srcb[f] + c * plane, W, L.taps[f]);
+      if (MODE >= 2) {        // per-pixel inputs of the output row that pipeline row k completes
+        int orow = y0 - 2 + k;
+        orow = orow < 0 ? 0 : (orow > H - 1 ? H - 1 : orow);
+        const unsigned pix = (unsigned)(orow * W + xo);
 #pragma unroll
-      for (int f = 0; f < NS; ++f)
+        for (int f = 0; f < NS; ++f) L.idv[f] = a.idloss[(size_t)(b * NS + f) * plane + pix];
+        if (MODE >= 3) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float v = blend_taps(tv[f][c], taps[f]);
-          s_x[f][c][py][px] = v;
-          if (own) a.warped[(((size_t)f * a.B + b) * 3 + c) * plane + off] = v;
+          for (int f = 0; f < NS; ++f) L.nz[f] = a.noise[(size_t)(f * a.B + b) * plane + pix];
         }
+      }
     }
-  }
-  __syncthreads();
+  };
 
-  // ---- phase 2: sliding-window SSIM + L1 down a 4-row strip per wave ----
-  const int cx = tid & 63, rg = tid >> 6;
-  const int gx = tx0 + cx;
-  float hy[3][3], hyy[3][3];            // [ring row][channel] horizontal 3-sums
-  float hx[3][NS][3], hxx[3][NS][3], hxy[3][NS][3];
-  float cy[2][3], cxv[2][NS][3];        // centre values of the two most recent rows
+  // two-row ring of horizontal sums + centre values of the previous row
+  float p_hy[2][3], p_hyy[2][3], p_hx[2][NS][3], p_hxx[2][NS][3], p_hxy[2][NS][3];
+  float c_y[3], c_x[NS][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    p_hy[0][c] = p_hy[1][c] = p_hyy[0][c] = p_hyy[1][c] = c_y[c] = 0.f;
+#pragma unroll
+    for (int f = 0; f < NS; ++f)
+      p_hx[0][f][c] = p_hx[1][f][c] = p_hxx[0][f][c] = p_hxx[1][f][c] = p_hxy[0][f][c] = p_hxy[1][f][c] = c_x[f][c] = 0.f;
+  }
   float acc = 0.f;
 
+  // consume pipeline row k from `cur`; EMIT: a full 3-row window is available
+  auto consume = [&](int k, const RowLoads<NS>& cur, bool emit_allowed) {
+    float y[3], xw[NS][3];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int r = rg * 4 + k;           // LDS row (tile row r-1)
-    const int slot = k % 3;
+    for (int c = 0; c < 3; ++c) y[c] = cur.yv[c];
+#pragma unroll
+    for (int f = 0; f < NS; ++f)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xw[f][c] = IDENT ? cur.xv[f][c] : blend_taps(cur.tv[f][c], cur.taps[f]);
+    const int r = y0 - 1 + k;
+    if (KEEP && !IDENT && k >= 1 && k <= FS_ROWS && r < H && col_out) {
+#pragma unroll
+      for (int f = 0; f < NS; ++f)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.warped[(((size_t)f * a.B + b) * 3 + c) * plane + (unsigned)(r * W + x)] = xw[f][c];
+    }
+    float ss[NS], l1[NS];
+#pragma unroll
+    for (int f = 0; f < NS; ++f) { ss[f] = 0.f; l1[f] = 0.f; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float y0 = s_y[c][r][cx], y1 = s_y[c][r][cx + 1], y2 = s_y[c][r][cx + 2];
-      hy[slot][c] = y0 + y1 + y2;
-      hyy[slot][c] = y0 * y0 + y1 * y1 + y2 * y2;
-      cy[k & 1][c] = y1;
+      const float hy = hsum3(y[c]);
+      const float hyy = hsum3(y[c] * y[c]);
+      float hx[NS], hxx[NS], hxy[NS];
 #pragma unroll
       for (int f = 0; f < NS; ++f) {
-        const float x0 = s_x[f][c][r][cx], x1 = s_x[f][c][r][cx + 1], x2 = s_x[f][c][r][cx + 2];
-        hx[slot][f][c] = x0 + x1 + x2;
-        hxx[slot][f][c] = x0 * x0 + x1 * x1 + x2 * x2;
-        hxy[slot][f][c] = x0 * y0 + x1 * y1 + x2 * y2;
-        cxv[k & 1][f][c] = x1;
+        hx[f] = hsum3(xw[f][c]);
+        hxx[f] = hsum3(xw[f][c] * xw[f][c]);
+        hxy[f] = hsum3(xw[f][c] * y[c]);
+      }
+      if (emit_allowed) {
+        const float sy = p_hy[0][c] + p_hy[1][c] + hy;
+        const float syy = p_hyy[0][c] + p_hyy[1][c] + hyy;
+#pragma unroll
+        for (int f = 0; f < NS; ++f) {
+          const float sx = p_hx[0][f][c] + p_hx[1][f][c] + hx[f];
+          const float sxx = p_hxx[0][f][c] + p_hxx[1][f][c] + hxx[f];
+          const float sxy = p_hxy[0][f][c] + p_hxy[1][f][c] + hxy[f];
+          ss[f] += ssim_from_sums(sx, sy, sxx, syy, sxy);
+          const float df = c_y[c] - c_x[f][c];
+          l1[f] += fast_sqrt(df * df + TD_L1_EPS2);
+        }
+      }
+      p_hy[0][c] = p_hy[1][c]; p_hy[1][c] = hy;
+      p_hyy[0][c] = p_hyy[1][c]; p_hyy[1][c] = hyy;
+      c_y[c] = y[c];
+#pragma unroll
+      for (int f = 0; f < NS; ++f) {
+        p_hx[0][f][c] = p_hx[1][f][c]; p_hx[1][f][c] = hx[f];
+        p_hxx[0][f][c] = p_hxx[1][f][c]; p_hxx[1][f][c] = hxx[f];
+        p_hxy[0][f][c] = p_hxy[1][f][c]; p_hxy[1][f][c] = hxy[f];
+        c_x[f][c] = xw[f][c];
       }
     }
-    if (k >= 2) {
-      const int gy = ty0 + rg * 4 + (k - 2);
-      const int pc = (k - 1) & 1;       // centre row = previous row
+    const int orow = r - 1;
+    if (emit_allowed && orow < H && col_out) {
+      const unsigned pix = (unsigned)(orow * W + x);
       float loss[NS];
 #pragma unroll
-      for (int f = 0; f < NS; ++f) {
-        float ss = 0.f, l1 = 0.f;
+      for (int f = 0; f < NS; ++f) loss[f] = 0.85f * (ss[f] * (1.f / 3.f)) + 0.15f * (l1[f] * (1.f / 3.f));
+      if (IDENT) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float sy = hy[0][c] + hy[1][c] + hy[2][c];
-          const float syy = hyy[0][c] + hyy[1][c] + hyy[2][c];
-          const float sx = hx[0][f][c] + hx[1][f][c] + hx[2][f][c];
-          const float sxx = hxx[0][f][c] + hxx[1][f][c] + hxx[2][f][c];
-          const float sxy = hxy[0][f][c] + hxy[1][f][c] + hxy[2][f][c];
-          ss += ssim_from_sums(sx, sy, sxx, syy, sxy);
-          const float df = cy[pc][c] - cxv[pc][f][c];
-          l1 += fast_sqrt(df * df + TD_L1_EPS2);
-        }
-        loss[f] = 0.85f * (ss * (1.f / 3.f)) + 0.15f * (l1 * (1.f / 3.f));
-      }
-      if (gy < H && gx < W) {
-        const size_t pix = (size_t)gy * W + gx;
-        if (IDENT) {
-#pragma unroll
-          for (int f = 0; f < NS; ++f) a.idloss_out[((size_t)b * NS + f) * plane + pix] = loss[f];
-        } else {
-          float best = 0.f;
-          int idx = 0;
-          bool have = false;
-          if (a.idloss != nullptr) {
-#pragma unroll
-            for (int f = 0; f < NS; ++f) {
-              float v = a.idloss[((size_t)b * NS + f) * plane + pix];
-              if (a.noise != nullptr) v += a.noise[((size_t)f * a.B + b) * plane + pix] * 1e-5f;
-              if (!have || v < best) { best = v; idx = f; have = true; }
-            }
-          }
-          const int base = (a.idloss != nullptr) ? NS : 0;
+        for (int f = 0; f < NS; ++f) a.idloss_out[(size_t)(b * NS + f) * plane + pix] = loss[f];
+      } else {
+        float best = 0.f;
+        int idx = 0;
+        bool have = false;
+        if (MODE >= 2) {
 #pragma unroll
           for (int f = 0; f < NS; ++f) {
-            if (!have || loss[f] < best) { best = loss[f]; idx = base + f; have = true; }
+            const float v = MODE >= 3 ? cur.idv[f] + cur.nz[f] * 1e-5f : cur.idv[f];
+            if (!have || v < best) { best = v; idx = f; have = true; }
           }
-          a.argmin[(size_t)b * plane + pix] = (uint8_t)idx;
-          if (a.min_map != nullptr) a.min_map[(size_t)b * plane + pix] = best;
-          acc += best;
         }
+        constexpr int base = (MODE >= 2) ? NS : 0;
+#pragma unroll
+        for (int f = 0; f < NS; ++f)
+          if (!have || loss[f] < best) { best = loss[f]; idx = base + f; have = true; }
+        a.argmin[(size_t)b * plane + pix] = (uint8_t)idx;
+        if (a.min_map != nullptr) a.min_map[(size_t)b * plane + pix] = best;
+        acc += best;
       }
     }
+  };
+
+  // ---- two-deep software pipeline over NK = FS_ROWS + 2 rows, ping-pong register sets ----
+  constexpr int NK = FS_ROWS + 2;
+  static_assert(NK % 2 == 0 && NK >= 6, "row pipeline is unrolled by two");
+  RowLoads<NS> LA, LB;
+  DispTaps DA, DB;
+  if (!IDENT) {
+    stage_a(0, DA);
+    stage_a(1, DB);
   }
+  stage_b(0, DA, LA);
+  // prologue: rows 0 and 1 only fill the window
+  if (!IDENT) stage_a(2, DA);
+  stage_b(1, DB, LB);
+  consume(0, LA, false);
+  if (!IDENT) stage_a(3, DB);
+  stage_b(2, DA, LA);
+  consume(1, LB, false);
+#pragma unroll 1
+  for (int k = 2; k < NK - 2; k += 2) {
+    if (!IDENT) stage_a(k + 2, DA);
+    stage_b(k + 1, DB, LB);
+    consume(k, LA, true);
+    if (!IDENT) stage_a(k + 3, DB);      // rows >= NK are clamped duplicates, never consumed
+    stage_b(k + 2, DA, LA);
+    consume(k + 1, LB, true);
+  }
+  stage_b(NK - 1, DB, LB);
+  consume(NK - 2, LA, true);
+  consume(NK - 1, LB, true);
 
   if (!IDENT) {
-    const float tot = block_sum(acc, s_red);
-    if (tid == 0) a.partial[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
+    const float tot = wave_sum(acc);
+    if (lane == 0) a.partial[task] = tot;
   }
 }
 
-template <int NS, bool IDENT>
-static int launch_fwd(const PhotoFwdArgs<NS>& a, hipStream_t st) {
-  dim3 grid((a.W + FT_W - 1) / FT_W, (a.H + FT_H - 1) / FT_H, a.B);
-  hipLaunchKernelGGL((photo_fwd_kernel<NS, IDENT>), grid, dim3(TD_THREADS), 0, st, a);
-  return record_launch_error(hipGetLastError(), IDENT ? "td_photo_identity" : "td_photo_fwd");
+static int fwd_tasks(int B, int H, int W, int* nstrips, int* nchunks) {
+  *nstrips = (W + FS_COLS - 1) / FS_COLS;
+  *nchunks = (H + FS_ROWS - 1) / FS_ROWS;
+  return B * (*nstrips) * (*nchunks);
+}
+
+template <int NS, int MODE, bool KEEP>
+static int launch_fwd(PhotoFwdArgs<NS>& a, hipStream_t st) {
+  a.ntasks = fwd_tasks(a.B, a.H, a.W, &a.nstrips, &a.nchunks);
+  const int blocks = (a.ntasks + FS_WAVES - 1) / FS_WAVES;
+  a.blocks_per_xcd = (blocks + 7) / 8;
+  hipLaunchKernelGGL((photo_fwd_kernel<NS, MODE, KEEP>), dim3(a.blocks_per_xcd * 8), dim3(FS_WAVES * 64), 0, st, a);
+  return record_launch_error(hipGetLastError(), MODE == 0 ? "td_photo_identity" : "td_photo_fwd");
 }
 
 template <int NS>
@@ -201,14 +331,25 @@ static int run_fwd(const float* tgt, const float* const* src, const float* disp,
   const double lo = 1.0 / (double)max_depth, hi = 1.0 / (double)min_depth;
   a.min_disp = (float)lo;
   a.disp_range = (float)(hi - lo);
-  return ident ? launch_fwd<NS, true>(a, st) : launch_fwd<NS, false>(a, st);
+  if (ident) return launch_fwd<NS, 0, false>(a, st);
+  const int mode = idloss == nullptr ? 1 : (noise == nullptr ? 2 : 3);
+  const bool keep = warped != nullptr;
+  switch (mode * 2 + (keep ? 1 : 0)) {
+    case 2: return launch_fwd<NS, 1, false>(a, st);
+    case 3: return launch_fwd<NS, 1, true>(a, st);
+    case 4: return launch_fwd<NS, 2, false>(a, st);
+    case 5: return launch_fwd<NS, 2, true>(a, st);
+    case 6: return launch_fwd<NS, 3, false>(a, st);
+    default: return launch_fwd<NS, 3, true>(a, st);
+  }
 }
 
 }  // namespace td
 
 extern "C" int td_photo_num_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return B * ((H + td::FT_H - 1) / td::FT_H) * ((W + td::FT_W - 1) / td::FT_W);
+  int ns, nc;
+  return td::fwd_tasks(B, H, W, &ns, &nc);
 }
 
 static int dispatch_fwd(const float* tgt, const float* const* src, int n_src, const float* disp,
@@ -230,7 +371,7 @@ extern "C" int td_photo_identity(const float* tgt, const float* const* src, int 
                                  int W, float* idloss, td_stream_t stream) {
   if (!tgt || !src || !idloss || n_src < 1 || n_src > TD_MAX_SRC || B <= 0) return TD_ERR_BAD_ARG;
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
-  if (H < 3 || W < 3) return TD_ERR_UNSUPPORTED;
+  if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   return dispatch_fwd(tgt, src, n_src, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, 1, 1,
                       0.1f, 100.f, nullptr, nullptr, nullptr, nullptr, idloss, true, stream);
 }
