@@ -166,6 +166,22 @@ int td_smooth_bwd(const float* disp, const float* img, const float* mean,
                   float* g_hat, float* dot_partial, float* d_disp, int accumulate,
                   td_stream_t stream);
 
+/* Element types of the activation kernels below. */
+#define TD_DTYPE_F32 0
+#define TD_DTYPE_BF16 1
+
+/*
+ * nn.MaxPool2d(kernel_size=5, stride=1, padding=2) of the CRP blocks
+ * (mono/model/mono_fm_joint/layers.py:208,213) on channels-last activations.
+ *   in / out / grad_* : [N,H,W,C] (NHWC memory, i.e. a torch channels_last tensor), C % 8 == 0
+ *   idx               : [N,H,W,C] uint8, window offset dy*5+dx of the selected element
+ *                       (ATen's tie-break: first maximum in row-major order; NaN propagates)
+ */
+int td_maxpool5_fwd(const void* in, int dtype, int N, int H, int W, int C, void* out, uint8_t* idx,
+                    td_stream_t stream);
+int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, int H, int W, int C,
+                    void* grad_in, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,26 @@
+"""GPU parity: hand-written 5x5 max-pool (channels_last) vs torch's max_pool2d, forward and backward."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (1, 256, 12, 40), (3, 8, 1, 5), (2, 64, 24, 80)])
+def test_maxpool5_matches_aten(dtype, N, C, H, W):
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    g = torch.Generator().manual_seed(0)
+    # quantised values create many exact ties: the arg-max tie-break must match ATen's
+    x = (torch.randint(0, 6, (N, C, H, W), generator=g).float() * 0.25).to(dtype)
+    x = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = ops.maxpool5(x)
+    yr = F.max_pool2d(xr, 5, 1, 2)
+    assert torch.equal(y, yr)                      # bit-exact selection
+    go = torch.randn(N, C, H, W, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    yr.backward(go)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2   # f32: summation order; bf16: f32 accumulation here, one rounding
+    assert float((x.grad.float() - xr.grad.float()).abs().max()) <= tol * max(1.0, float(xr.grad.float().abs().max()))

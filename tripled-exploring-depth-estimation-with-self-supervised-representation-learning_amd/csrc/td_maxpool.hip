@@ -1,0 +1,156 @@
+// 5x5 / stride 1 / pad 2 max-pooling for channels-last (NHWC) activations -- the 16 pools of the
+// CRP blocks (reference: mono/model/mono_fm_joint/layers.py:208, nn.MaxPool2d(5, 1, 2)).
+// Forward keeps a 1-byte window offset per element (ATen keeps an int64 index); backward is a
+// gather over the 25 outputs whose window contains the input element -- no atomics.
+// Tie-break and NaN handling follow ATen's max_pool2d: row-major scan, strict '>', NaN wins.
+#include <hip/hip_bf16.h>
+
+#include "td_common.h"
+
+namespace td {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<__hip_bfloat16> { uint4 raw; };
+template <> struct Vec8<float> { float4 lo, hi; };
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-nearest-even, NaN kept
+  return __builtin_bit_cast(unsigned short, __float2bfloat16(f));
+}
+
+__device__ __forceinline__ void load8(const __hip_bfloat16* p, float* v) {
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = bf2f((unsigned short)(w[i] & 0xffff)); v[2 * i + 1] = bf2f((unsigned short)(w[i] >> 16)); }
+}
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(__hip_bfloat16* p, const float* v) {
+  uint4 r;
+  r.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+  r.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  r.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+  r.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// one thread = one output pixel x 8 consecutive channels
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_kernel(const T* __restrict__ in, int N, int H, int W, int C,
+                                                                  T* __restrict__ out, uint8_t* __restrict__ idx) {
+  const int c8 = C >> 3;
+  const long long gid = (long long)blockIdx.x * TD_THREADS + threadIdx.x;
+  const long long total = (long long)N * H * W * c8;
+  if (gid >= total) return;
+  const int cv = (int)(gid % c8);
+  const long long pix = gid / c8;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+  float best[8];
+  unsigned char arg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = 12; }
+  const T* base = in + (size_t)n * H * W * C + (size_t)cv * 8;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int yy = y + dy - 2;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int xx = x + dx - 2;
+      if (xx < 0 || xx >= W) continue;
+      float v[8];
+      load8(base + ((size_t)yy * W + xx) * C, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; arg[i] = (unsigned char)(dy * 5 + dx); }
+      }
+    }
+  }
+  const size_t o = ((size_t)pix) * C + (size_t)cv * 8;
+  store8(out + o, best);
+  uint2 packed;
+  packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
+  packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
+  *reinterpret_cast<uint2*>(idx + o) = packed;
+}
+
+// one thread = one input pixel x 8 channels: sum the gradients of the outputs that selected it
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __restrict__ gout,
+                                                                  const uint8_t* __restrict__ idx, int N, int H,
+                                                                  int W, int C, T* __restrict__ gin) {
+  const int c8 = C >> 3;
+  const long long gid = (long long)blockIdx.x * TD_THREADS + threadIdx.x;
+  const long long total = (long long)N * H * W * c8;
+  if (gid >= total) return;
+  const int cv = (int)(gid % c8);
+  const long long pix = gid / c8;
+  const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const size_t nb = (size_t)n * H * W * C + (size_t)cv * 8;
+#pragma unroll
+  for (int dy = 0; dy < 5; ++dy) {
+    const int oy = y - (dy - 2);                       // output whose window offset dy lands on y
+    if (oy < 0 || oy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      const int ox = x - (dx - 2);
+      if (ox < 0 || ox >= W) continue;
+      const size_t o = nb + ((size_t)oy * W + ox) * C;
+      const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+      const unsigned want = (unsigned)(dy * 5 + dx);
+      const unsigned w0 = pk.x, w1 = pk.y;
+      const bool hit0 = ((w0 & 0xff) == want) | (((w0 >> 8) & 0xff) == want) | (((w0 >> 16) & 0xff) == want) | ((w0 >> 24) == want);
+      const bool hit1 = ((w1 & 0xff) == want) | (((w1 >> 8) & 0xff) == want) | (((w1 >> 16) & 0xff) == want) | ((w1 >> 24) == want);
+      if (!(hit0 | hit1)) continue;
+      float g[8];
+      load8(gout + o, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (((w0 >> (8 * i)) & 0xff) == want) acc[i] += g[i];
+        if (((w1 >> (8 * i)) & 0xff) == want) acc[4 + i] += g[4 + i];
+      }
+    }
+  }
+  store8(gin + (size_t)pix * C + (size_t)cv * 8, acc);
+}
+
+template <typename T>
+static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, int W, int C, void* o, void* o2, hipStream_t st) {
+  const long long total = (long long)N * H * W * (C / 8);
+  const unsigned blocks = (unsigned)((total + TD_THREADS - 1) / TD_THREADS);
+  if (fwd)
+    hipLaunchKernelGGL((maxpool5_fwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, N, H, W, C, (T*)o, (uint8_t*)o2);
+  else
+    hipLaunchKernelGGL((maxpool5_bwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, (T*)o);
+  return record_launch_error(hipGetLastError(), fwd ? "td_maxpool5_fwd" : "td_maxpool5_bwd");
+}
+
+}  // namespace td
+
+extern "C" int td_maxpool5_fwd(const void* in, int dtype, int N, int H, int W, int C, void* out, uint8_t* idx,
+                               td_stream_t stream) {
+  if (!in || !out || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return TD_ERR_BAD_ARG;
+  if (C % 8 != 0) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16) return td::run_maxpool<__hip_bfloat16>(true, in, nullptr, N, H, W, C, out, idx, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32) return td::run_maxpool<float>(true, in, nullptr, N, H, W, C, out, idx, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, int H, int W, int C,
+                               void* grad_in, td_stream_t stream) {
+  if (!grad_out || !idx || !grad_in || N <= 0 || H <= 0 || W <= 0 || C <= 0) return TD_ERR_BAD_ARG;
+  if (C % 8 != 0) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16) return td::run_maxpool<__hip_bfloat16>(false, grad_out, idx, N, H, W, C, grad_in, nullptr, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32) return td::run_maxpool<float>(false, grad_out, idx, N, H, W, C, grad_in, nullptr, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}

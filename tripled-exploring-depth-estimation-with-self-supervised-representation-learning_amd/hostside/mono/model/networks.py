@@ -311,10 +311,19 @@ class CRPBlock(nn.Module):
         self.n_stages = n_stages
         self.maxpool = nn.MaxPool2d(kernel_size=5, stride=1, padding=2)
 
+    def _pool(self, t):
+        # channels-last HIP activations go to the hand-written 5x5 kernel (1-byte arg-max,
+        # gather-form backward); anything else (CPU tests, NCHW) to ATen's max_pool2d
+        if t.is_cuda and t.is_contiguous(memory_format=torch.channels_last) and t.shape[1] % 8 == 0 \
+                and t.dtype in (torch.float32, torch.bfloat16):
+            from tripled_amd import ops
+            return ops.maxpool5(t)
+        return self.maxpool(t)
+
     def forward(self, x):
         top = x
         for i in range(self.n_stages):
-            top = getattr(self, "{}_{}".format(i + 1, "pointwise"))(self.maxpool(top))
+            top = getattr(self, "{}_{}".format(i + 1, "pointwise"))(self._pool(top))
             x = top + x
         return x
 

@@ -35,7 +35,11 @@ SIGNATURES = {
     "td_smooth_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "td_smooth_finish": (_I, [_P, _I, _I, _I, _F, _P, _P]),
     "td_smooth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _P]),
+    "td_maxpool5_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "td_maxpool5_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
 }
+
+DTYPE_CODES = {torch.float32: 0, torch.bfloat16: 1}
 
 
 class NativeLibraryError(RuntimeError):

@@ -165,3 +165,45 @@ def smooth_loss(disp, img_at_scale, normalize=True, weight=1.0):
     if img.shape[2:] != disp.shape[2:]:
         raise ValueError("img_at_scale must already have disp's spatial size")
     return _SmoothLoss.apply(disp, img, normalize, weight)
+
+
+def _raw(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _MaxPool5(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = native.load()
+        N, C, H, W = x.shape
+        out = torch.empty_like(x, memory_format=torch.channels_last)
+        idx = torch.empty((N, H, W, C), device=x.device, dtype=torch.uint8)
+        native.check(lib.td_maxpool5_fwd(_raw(x), native.DTYPE_CODES[x.dtype], N, H, W, C, _raw(out), _raw(idx),
+                                         native.stream()), "td_maxpool5_fwd")
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        (idx,) = ctx.saved_tensors
+        N, H, W, C = idx.shape
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty_like(g, memory_format=torch.channels_last)
+        native.check(lib.td_maxpool5_bwd(_raw(g), _raw(idx), native.DTYPE_CODES[g.dtype], N, H, W, C, _raw(gin),
+                                         native.stream()), "td_maxpool5_bwd")
+        return gin
+
+
+def maxpool5_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def maxpool5(x):
+    """nn.MaxPool2d(5, 1, 2) on a channels_last CUDA tensor (reference: layers.py:208,213)."""
+    if not maxpool5_supported(x):
+        raise native.NativeLibraryError("maxpool5 needs a channels_last f32/bf16 HIP tensor with C % 8 == 0")
+    return _MaxPool5.apply(x)
