@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-graph", action="store_true", help="do not capture the step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--syncbn", default="config", choices=["config", "on", "off"])
@@ -277,7 +278,10 @@ def main():
                 "parallelism": "dp%d" % world, "hip_graph": graphed,
                 "syncbn": bool(use_syncbn and world > 1), "final_loss": round(final_loss, 6)},
         }
-        kern = roofline_of_hot_kernels(cfg, batch)
+        kern = roofline_of_hot_kernels(cfg, batch) if not args.no_roofline else None
+        if kern is None:
+            print(json.dumps(line))
+            return
         dom = max(kern, key=lambda k: kern[k]["seconds"])
         ach = kern[dom]["bytes"] / kern[dom]["seconds"] / 1e9
         traffic = None

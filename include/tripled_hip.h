@@ -182,6 +182,26 @@ int td_maxpool5_fwd(const void* in, int dtype, int N, int H, int W, int C, void*
 int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, int H, int W, int C,
                     void* grad_in, td_stream_t stream);
 
+/*
+ * Edge-aware regulariser on C-channel feature maps: get_feature_regularization_loss,
+ * mono/model/mono_fm_joint/net.py:309-330 (six stencil terms |d_k F| * exp(-a * mean_c |d_k I|)).
+ *
+ * td_edge_weights: Wt[b,k,y,x] = scale6[k] * exp(-a * mean_c |d_k img|), 0 where term k has no anchor
+ *   at (y,x); k = dx, dy, dxx, dxy, dyx, dyy.  img [B,3,h,w] is the area-resized target; scale6 (HOST
+ *   array) carries coefficient / element-count of each term, so that
+ *       loss = sum over anchors, channels, k of |d_k F| * Wt
+ * td_featreg_fwd: partial[td_featreg_num_blocks] per-block sums of that (finish with td_sum_scaled).
+ * td_featreg_bwd: grad = gscale[0] * d loss / d feat, same dtype/layout as feat.
+ *   feat: [B,h,w,C] channels-last memory, C % 8 == 0, dtype TD_DTYPE_F32 or TD_DTYPE_BF16.
+ */
+int td_edge_weights(const float* img, int B, int h, int w, float a, const float* scale6, float* Wt,
+                    td_stream_t stream);
+int td_featreg_num_blocks(int B, int h, int w, int C);
+int td_featreg_fwd(const void* feat, int dtype, const float* Wt, int B, int h, int w, int C,
+                   float* partial, td_stream_t stream);
+int td_featreg_bwd(const void* feat, int dtype, const float* Wt, const float* gscale, int B, int h, int w,
+                   int C, void* grad, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

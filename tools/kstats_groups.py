@@ -5,7 +5,7 @@ import re
 import sys
 
 GROUPS = [
-    ("hip loss kernels (td::)", r"td::"),
+    ("hip kernels (td::)", r"(^|[^s])td::"),
     ("conv (MIOpen igemm/winograd/gemm)", r"igemm|Cijk|miopen.*[Cc]onv|gridwise|naive_conv|Winograd|winograd|sp3|gfx9.*conv|conv_|kernel_gemm|batched_transpose"),
     ("MIOpen tensor ops (cast/set/add)", r"SubTensorOp|Op1dTensor|Op2dTensor|Op4dTensor|OpTensor"),
     ("batchnorm", r"BatchNorm|batch_norm"),

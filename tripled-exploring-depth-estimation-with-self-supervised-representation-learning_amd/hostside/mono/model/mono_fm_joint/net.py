@@ -143,6 +143,12 @@ class mono_fm_joint(nn.Module):
     # ------------------------------------------------------------------ auxiliary terms (torch ops)
     def get_feature_regularization_loss(self, feature, img):
         """net.py:309-330: -dis * first-order + cvt * second-order edge-aware terms (a = 1)."""
+        if feature.is_cuda:
+            from tripled_amd import ops
+            h, w = feature.shape[2:]
+            if ops.featreg_supported(feature) and img.shape[2] % h == 0 and img.shape[3] % w == 0:
+                # fused HIP path: reads the (bf16/f32, channels-last) feature map directly
+                return ops.feature_regularization(feature, ops.area_downsample(img, h, w), self.opt.dis, self.opt.cvt)
         feature = feature.float()
         img = F.adaptive_avg_pool2d(img, feature.shape[2:])
         f_dx, f_dy = self.gradient(feature)

@@ -207,3 +207,60 @@ def maxpool5(x):
     if not maxpool5_supported(x):
         raise native.NativeLibraryError("maxpool5 needs a channels_last f32/bf16 HIP tensor with C % 8 == 0")
     return _MaxPool5.apply(x)
+
+
+def edge_weights(img_at_scale, a, scale6):
+    """Per-pixel, per-term image weights scale_k * exp(-a * mean_c |d_k I|) -> [B,6,h,w] (no gradient)."""
+    import ctypes
+    lib = native.load()
+    img = _f32c(img_at_scale.detach())
+    B, _, h, w = img.shape
+    out = torch.empty(B, 6, h, w, device=img.device, dtype=torch.float32)
+    arr = (ctypes.c_float * 6)(*[float(v) for v in scale6])
+    native.check(lib.td_edge_weights(native.ptr(img), B, h, w, float(a), arr, native.ptr(out), native.stream()),
+                 "td_edge_weights")
+    return out
+
+
+class _FeatReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, Wt):
+        lib = native.load()
+        B, C, h, w = feat.shape
+        nblk = lib.td_featreg_num_blocks(B, h, w, C)
+        partial = torch.empty(nblk, device=feat.device, dtype=torch.float32)
+        loss = torch.empty(1, device=feat.device, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_featreg_fwd(_raw(feat), native.DTYPE_CODES[feat.dtype], native.ptr(Wt), B, h, w, C,
+                                        native.ptr(partial), st), "td_featreg_fwd")
+        native.check(lib.td_sum_scaled(native.ptr(partial), nblk, 1.0, native.ptr(loss), st), "td_sum_scaled")
+        ctx.save_for_backward(feat, Wt)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        feat, Wt = ctx.saved_tensors
+        B, C, h, w = feat.shape
+        grad = torch.empty_like(feat, memory_format=torch.channels_last)
+        gs = _f32c(g.reshape(1))
+        native.check(lib.td_featreg_bwd(_raw(feat), native.DTYPE_CODES[feat.dtype], native.ptr(Wt), native.ptr(gs),
+                                        B, h, w, C, _raw(grad), native.stream()), "td_featreg_bwd")
+        return grad, None
+
+
+def featreg_supported(feat):
+    return (feat.is_cuda and feat.dim() == 4 and feat.dtype in native.DTYPE_CODES and feat.shape[1] % 8 == 0
+            and feat.shape[2] >= 3 and feat.shape[3] >= 3 and feat.is_contiguous(memory_format=torch.channels_last))
+
+
+def feature_regularization(feat, img_at_scale, dis, cvt):
+    """-dis * smooth1 + cvt * smooth2 of get_feature_regularization_loss
+    (mono/model/mono_fm_joint/net.py:309-330) on a channels_last feature map, fused."""
+    B, C, h, w = feat.shape
+    n = float(B * C)
+    counts = [n * h * (w - 1), n * (h - 1) * w, n * h * (w - 2), n * (h - 1) * (w - 1), n * (h - 1) * (w - 1),
+              n * (h - 2) * w]
+    coef = [-dis, -dis, cvt, cvt, cvt, cvt]
+    Wt = edge_weights(img_at_scale, 1.0, [c / k for c, k in zip(coef, counts)])
+    return _FeatReg.apply(feat, Wt)
