@@ -202,6 +202,20 @@ int td_featreg_fwd(const void* feat, int dtype, const float* Wt, int B, int h, i
 int td_featreg_bwd(const void* feat, int dtype, const float* Wt, const float* gscale, int B, int h, int w,
                    int C, void* grad, td_stream_t stream);
 
+/*
+ * Masked photometric reconstruction term of the in-painting auto-encoder
+ * (mono/model/mono_fm_joint_inpaint/net.py:80-91):
+ *     S = sum_p hole[p] * (0.85 * mean_c SSIM_c(x, y)(p) + 0.15 * mean_c sqrt((y - x)^2 + 1e-6))
+ *   x (prediction), y (target): [B,3,h,w] f32 planar; hole: [B,h,w] f32 per-pixel weight
+ * td_recon_fwd: partial[td_recon_num_tasks] per-wave sums of S (finish with td_sum_scaled);
+ * td_recon_bwd: dx = gscale[0] * dS/dx, [B,3,h,w].
+ */
+int td_recon_num_tasks(int B, int h, int w);
+int td_recon_fwd(const float* x, const float* y, const float* hole, int B, int h, int w,
+                 float* partial, td_stream_t stream);
+int td_recon_bwd(const float* x, const float* y, const float* hole, const float* gscale, int B, int h,
+                 int w, float* dx, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,2 +1,1 @@
-timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "amdgpu.ids" | tail -2
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --miopen-find off 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" | tail -1 | cut -c1-400
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --miopen-find off 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" | tail -1 | cut -c1-330

@@ -36,19 +36,6 @@ struct PhotoFwdArgs {
   float min_disp, disp_range;
 };
 
-// value of the lane to the left / right (wave-wide shift by one lane; the edge lanes receive 0 --
-// they only ever feed halo columns whose results are discarded).  old = 0 + bound_ctrl lets the
-// compiler fold the shift into the consuming v_add_f32 (v_add_f32_dpp).
-__device__ __forceinline__ float lane_left(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */,
-                                                               0xf, 0xf, true));
-}
-__device__ __forceinline__ float lane_right(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */,
-                                                               0xf, 0xf, true));
-}
-__device__ __forceinline__ float hsum3(float v) { return (lane_left(v) + v) + lane_right(v); }
-
 // per-row vertical source rows of the bilinear up-sampling (wave-uniform)
 struct UpRow {
   int o0, o1;       // element offsets of the two low-res rows

@@ -57,8 +57,14 @@ class mono_fm_joint_inpaint(mono_fm_joint):
         size = list(res_img.shape[2:])
         t_rs = F.interpolate(inputs[("color", 0, 0)], size, mode="bilinear", align_corners=False)
         hole = 1 - F.interpolate(inputs[("mask", 0, 0)], size, mode="bilinear", align_corners=False)
-        loss = self.compute_reprojection_loss(res_img, t_rs)
-        loss = torch.sum(loss * hole) / torch.sum(hole)
+        if res_img.is_cuda and size[0] >= 3 and size[1] >= 3:
+            # fused HIP path: SSIM + L1 + masked sum in one streaming kernel (and one for the gradient);
+            # the 3 mask channels weight the same per-pixel loss, so they collapse to one plane
+            from tripled_amd import ops
+            loss = ops.masked_reconstruction_sum(res_img, t_rs, hole.sum(1)) / torch.sum(hole)
+        else:
+            loss = self.compute_reprojection_loss(res_img, t_rs)
+            loss = torch.sum(loss * hole) / torch.sum(hole)
         return loss / len(opt.scales) * opt.get("img_reconstruct_weight", 1)
 
     def compute_losses(self, inputs, outputs, features):

@@ -41,6 +41,9 @@ SIGNATURES = {
     "td_featreg_num_blocks": (_I, [_I, _I, _I, _I]),
     "td_featreg_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "td_featreg_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "td_recon_num_tasks": (_I, [_I, _I, _I]),
+    "td_recon_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "td_recon_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
 }
 
 DTYPE_CODES = {torch.float32: 0, torch.bfloat16: 1}

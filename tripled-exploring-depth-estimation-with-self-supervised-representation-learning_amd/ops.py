@@ -264,3 +264,39 @@ def feature_regularization(feat, img_at_scale, dis, cvt):
     coef = [-dis, -dis, cvt, cvt, cvt, cvt]
     Wt = edge_weights(img_at_scale, 1.0, [c / k for c, k in zip(coef, counts)])
     return _FeatReg.apply(feat, Wt)
+
+
+class _ReconSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, hole):
+        lib = native.load()
+        B, _, h, w = x.shape
+        n = lib.td_recon_num_tasks(B, h, w)
+        partial = torch.empty(n, device=x.device, dtype=torch.float32)
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_recon_fwd(native.ptr(x), native.ptr(y), native.ptr(hole), B, h, w, native.ptr(partial), st),
+                     "td_recon_fwd")
+        native.check(lib.td_sum_scaled(native.ptr(partial), n, 1.0, native.ptr(out), st), "td_sum_scaled")
+        ctx.save_for_backward(x, y, hole)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        x, y, hole = ctx.saved_tensors
+        B, _, h, w = x.shape
+        dx = torch.empty_like(x)
+        gs = _f32c(g.reshape(1))
+        native.check(lib.td_recon_bwd(native.ptr(x), native.ptr(y), native.ptr(hole), native.ptr(gs), B, h, w,
+                                      native.ptr(dx), native.stream()), "td_recon_bwd")
+        return dx, None, None
+
+
+def masked_reconstruction_sum(pred, target, hole):
+    """sum_p hole[p] * (0.85 * mean_c SSIM(pred, target) + 0.15 * mean_c robust_l1) with gradient to
+    ``pred`` (mono/model/mono_fm_joint_inpaint/net.py:84-89).  pred/target [B,3,h,w], hole [B,h,w]."""
+    if pred.shape[2] < 3 or pred.shape[3] < 3:
+        raise native.NativeLibraryError("masked_reconstruction_sum needs h, w >= 3")
+    pred = pred.float().contiguous()          # (channels-last bf16 decoder output -> planar f32)
+    return _ReconSum.apply(pred, _f32c(target.detach()), _f32c(hole.detach()))
