@@ -136,6 +136,7 @@ def roofline_of_hot_kernels(cfg, batch):
     idloss = torch.empty(B, n_src, H, W, device=dev)
     noise = torch.randn(n_src, B, H, W, device=dev)
     argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+    coef = torch.empty(B, 9, H, W, device=dev)
     part = torch.empty(lib.td_photo_num_blocks(B, H, W), device=dev)
     d_up = torch.empty(B, H, W, device=dev)
     dpp = torch.empty(lib.td_photo_bwd_num_blocks(B, H, W), n_src * 12, device=dev)
@@ -154,11 +155,11 @@ def roofline_of_hot_kernels(cfg, batch):
         def fwd():
             native.check(lib.td_photo_fwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
                                           native.ptr(idloss), native.ptr(noise), B, H, W, hs, ws, 0.1, 100.0,
-                                          native.ptr(argmin), None, None, native.ptr(part), st), "fwd")
+                                          native.ptr(argmin), None, None, native.ptr(part), native.ptr(coef), st), "fwd")
 
         def bwd():
             native.check(lib.td_photo_bwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
-                                          native.ptr(argmin), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
+                                          native.ptr(argmin), native.ptr(coef), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
                                           0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
 
         t_f, t_b = time_kernel(fwd), time_kernel(bwd)

@@ -82,20 +82,24 @@ int td_photo_identity(const float* tgt, const float* const* src, int n_src,
  *   argmin    [B,H,W] uint8 (out): index into the candidate list (reference: int64 "min_index")
  *   warped    [n_src,B,3,H,W] (out, nullable): the warped sources, outputs[("color", f, s)]
  *   min_map   [B,H,W] (out, nullable): per-pixel minimum
- *   partial   [td_photo_num_blocks] (out): per-block sums of the per-pixel minimum; the loss is
+ *   partial   [td_photo_num_blocks] (out): per-wave-task sums of the per-pixel minimum; the loss is
  *             sum(partial) / (B*H*W) / n_scales  (td_sum_scaled finishes it deterministically)
+ *   coef      [B,9,H,W] (out, nullable; pass it when a backward will follow): per pixel p and channel c
+ *             the SSIM-adjoint coefficients (alpha, beta, gamma) of the warped frame the arg-min selected
+ *             (zeros where an identity term won), with  d SSIM_p / d x_q = (alpha + beta x_q + gamma y_q)/9
+ *             for every member q of p's 3x3 window.
  */
 int td_photo_fwd(const float* tgt, const float* const* src, int n_src,
                  const float* disp, const float* P, const float* invK,
                  const float* idloss, const float* noise,
                  int B, int H, int W, int hs, int ws,
                  float min_depth, float max_depth,
-                 uint8_t* argmin, float* warped, float* min_map, float* partial,
+                 uint8_t* argmin, float* warped, float* min_map, float* partial, float* coef,
                  td_stream_t stream);
 
 /*
  * Backward of td_photo_fwd w.r.t. disp and P (what autograd derives in the reference from the
- * same lines).  Everything is recomputed in-kernel from the inputs; only argmin is saved.
+ * same lines).  The warp is recomputed in-kernel; argmin and coef come from the forward.
  *   gscale    device scalar: d(total)/d(loss_s) as handed over by autograd
  *   inv_count 1 / (B*H*W*n_scales)  (the mean and the /len(scales) of net.py:117)
  *   d_up      [B,H,W] (out, workspace): gradient w.r.t. the UPSAMPLED disparity
@@ -104,7 +108,7 @@ int td_photo_fwd(const float* tgt, const float* const* src, int n_src,
  */
 int td_photo_bwd(const float* tgt, const float* const* src, int n_src,
                  const float* disp, const float* P, const float* invK,
-                 const uint8_t* argmin, int automask,
+                 const uint8_t* argmin, const float* coef, int automask,
                  const float* gscale, float inv_count,
                  int B, int H, int W, int hs, int ws,
                  float min_depth, float max_depth,

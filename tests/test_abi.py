@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu():
     lib = native.load()
     assert lib.td_abi_version() == 1
     assert lib.td_photo_num_blocks(12, 192, 640) == 12 * 24 * 11      # wave tasks: 8-row x 62-column strips
-    assert lib.td_photo_bwd_num_blocks(12, 192, 640) == 12 * 24 * 10
+    assert lib.td_photo_bwd_num_blocks(12, 192, 640) == 12 * 24 * 11  # 8-row x 60-column strips
     assert lib.td_smooth_num_blocks(12, 96, 320) == 12 * 6 * 5
     # null pointers / bad sizes are rejected before any launch
     assert lib.td_sum_scaled(None, 4, 1.0, None, None) == -1

@@ -206,6 +206,30 @@ __device__ __forceinline__ float ssim_from_sums(float sx, float sy, float sxx, f
   return fminf(fmaxf(s, 0.f), 1.f);
 }
 
+// SSIM loss value plus the coefficients of its adjoint w.r.t. the prediction x: for every member q
+// of the 3x3 window,  d SSIM_loss / d x_q = (alpha + beta * x_q + gamma * y_q) / 9
+// (zero outside the clamp's open interval, like torch.clamp's backward on the closed one).
+__device__ __forceinline__ float ssim_with_adjoint(float sx, float sy, float sxx, float syy, float sxy,
+                                                   float& alpha, float& beta, float& gamma) {
+  const float k = 1.f / 9.f;
+  const float mx = sx * k, my = sy * k;
+  const float vx = sxx * k - mx * mx;
+  const float vy = syy * k - my * my;
+  const float cxy = sxy * k - mx * my;
+  const float A1 = 2.f * mx * my + TD_SSIM_C1, A2 = 2.f * cxy + TD_SSIM_C2;
+  const float B1 = mx * mx + my * my + TD_SSIM_C1, B2 = vx + vy + TD_SSIM_C2;
+  const float n = A1 * A2, d = B1 * B2;
+  const float invd = fast_rcp(d);
+  const float q = n * invd;
+  const float s = (1.f - q) * 0.5f;
+  const float sc = (s >= 0.f && s <= 1.f) ? invd : 0.f;
+  alpha = -sc * (my * (A2 - A1) - q * mx * (B2 - B1));
+  beta = sc * q * B1;
+  gamma = -sc * A1;
+  return fminf(fmaxf(s, 0.f), 1.f);
+}
+
+
 // value of the lane to the left / right (wave-wide shift by one lane; the edge lanes receive 0 --
 // they only ever feed halo columns whose results are discarded).  old = 0 + bound_ctrl lets the
 // compiler fold the shift into the consuming v_add_f32 (v_add_f32_dpp).

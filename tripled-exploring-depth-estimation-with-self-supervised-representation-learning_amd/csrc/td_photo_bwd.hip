@@ -1,22 +1,22 @@
-// Fused photometric backward (recompute-in-kernel).  Per 8x64 tile and per source frame:
-//   1. re-warp the source over the tile + 2-pixel halo into LDS,
-//   2. for every pixel p of tile + 1-pixel halo whose arg-min selected this frame, form the
-//      SSIM window statistics and store the three coefficients (alpha, beta, gamma) per
-//      channel such that d SSIM_p / d x_q = alpha_p + beta_p * x_q + gamma_p * y_q for any
-//      window member q  (a box-filter adjoint instead of a 9x9 scatter),
-//   3. every tile pixel q box-sums the coefficients of its neighbours (with the reflection
-//      padding's multiplicities), adds the robust-L1 term, and chains through the bilinear
-//      sampler, the projection and the depth to d(loss)/d(upsampled disparity) and dL/dP.
-// dL/dP is block-reduced and written per block; d_up is written once per pixel (no atomics,
-// bit-reproducible).
+// Fused photometric backward, streaming form.  The forward leaves, per pixel, the three SSIM-adjoint
+// coefficients per channel of the warped frame its arg-min selected
+// (d SSIM_p / d x_q = (alpha_p + beta_p x_q + gamma_p y_q) / 9 for every member q of p's window), so the
+// adjoint of the 3x3 windows is a box filter over that field and nothing is scattered.
+// A wave owns a strip of 62 columns and marches down the rows, once per source frame; per row it
+//   1. re-warps the source (two-deep load pipeline as in the forward) and forms d x_c / d(u, v),
+//   2. box-filters the coefficient field (horizontal: DPP lane shifts, vertical: two-row register
+//      ring; reflection padding = integer multiplicities) -> d loss / d warped pixel one row back,
+//      adds the robust-L1 adjoint,
+//   3. chains through the bilinear sampler, the projection and the depth.
+// No LDS, no barriers, no atomics: d_up is written once per pixel per frame (first frame stores,
+// later frames add), dL/dP is accumulated in registers and written once per wave.
 #include "td_common.h"
 
 namespace td {
 
-constexpr int BT_H = TD_BWD_TILE_H;
-constexpr int BT_W = TD_TILE_W;
-constexpr int B2H = BT_H + 4, B2W = BT_W + 4;   // tile + halo 2 (values)
-constexpr int B1H = BT_H + 2, B1W = BT_W + 2;   // tile + halo 1 (coefficients)
+constexpr int BS_ROWS = 8;        // gradient rows per wave task
+constexpr int BS_COLS = 62;       // gradient columns per wave task (1-column halo on both sides)
+constexpr int BS_WAVES = 4;
 
 template <int NS>
 struct PhotoBwdArgs {
@@ -26,225 +26,204 @@ struct PhotoBwdArgs {
   const float* P;
   const float* invK;
   const uint8_t* argmin;
+  const float* coef;
   const float* gscale;
   float* d_up;
   float* dP_partial;
   int B, H, W, hs, ws;
   int n_ident;            // candidates preceding the warped ones (n_src when automasking, else 0)
+  int nstrips, nchunks, ntasks, blocks_per_xcd;
   float inv_count;
   float min_disp, disp_range;
 };
 
 template <int NS>
-__global__ __launch_bounds__(TD_THREADS) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
-  __shared__ float s_y[3][B2H][B2W];
-  __shared__ float s_x[3][B2H][B2W];
-  __shared__ float s_cf[9][B1H][B1W];     // [channel*3 + {alpha,beta,gamma}]
-  __shared__ float s_cam[9 + NS * 12];
-  __shared__ float s_red[4][12];
+__global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int bid = (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3);
+  const int task = bid * BS_WAVES + wave;
+  if (task >= a.ntasks) return;
+  const int strip = task % a.nstrips;
+  const int chunk = (task / a.nstrips) % a.nchunks;
+  const int b = task / (a.nstrips * a.nchunks);
 
-  const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int ty0 = blockIdx.y * BT_H, tx0 = blockIdx.x * BT_W;
   const int H = a.H, W = a.W;
-  const size_t plane = (size_t)H * W;
+  const unsigned plane = (unsigned)(H * W);
+  const int x = strip * BS_COLS - 1 + lane;          // padded-domain column of this lane
+  const int y0 = chunk * BS_ROWS;
+  const bool col_in = x >= 0 && x < W;
+  const bool col_out = lane >= 1 && lane <= BS_COLS && col_in;
+  const int xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+  const float wl = (x == 1) ? 2.f : 1.f, wr = (x == W - 2) ? 2.f : 1.f;
 
-  if (tid < 9) s_cam[tid] = a.invK[(size_t)b * 16 + (tid / 3) * 4 + (tid % 3)];
-  if (tid >= 64 && tid < 64 + NS * 12) {
-    const int k = tid - 64, f = k / 12, e = k % 12;
-    s_cam[9 + k] = a.P[((size_t)f * a.B + b) * 12 + e];
-  }
-  const float ry = (float)a.hs / (float)H, rx = (float)a.ws / (float)W;
+  const float* tgtb = a.tgt + (size_t)b * 3 * plane;
+  const float* cfb = a.coef + (size_t)b * 9 * plane;
+  const uint8_t* amb = a.argmin + (size_t)b * plane;
+  float* dupb = a.d_up + (size_t)b * plane;
   const float* dispb = a.disp + (size_t)b * a.hs * a.ws;
-  const float g = a.gscale[0] * a.inv_count;          // d total / d (per-pixel min)
-  const float g_ssim = g * 0.85f / 3.f / 9.f;          // .. / d (window-mean member), per channel
-  const float g_l1 = g * 0.15f / 3.f;
-
-  // target tile (halo 2) once
-  for (int pos = tid; pos < B2H * B2W; pos += TD_THREADS) {
-    const int py = pos / B2W, px = pos - py * B2W;
-    const int qy = reflect1(ty0 + py - 2, H), qx = reflect1(tx0 + px - 2, W);
+  float ik[9];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      s_y[c][py][px] = a.tgt[((size_t)b * 3 + c) * plane + (size_t)qy * W + qx];
-  }
-
-  // the two tile pixels this thread owns: rows (tid>>6)*2 + {0,1}, column tid&63
-  const int ox = tid & 63, oyb = (tid >> 6) * 2;
-  float dup[2] = {0.f, 0.f};
+  for (int i = 0; i < 9; ++i) ik[i] = a.invK[b * 16 + (i / 3) * 4 + (i % 3)];
+  const UpIdx ux = up_index(xc, (float)a.ws / (float)W, a.ws);
+  const float ratio_y = (float)a.hs / (float)H;
+  const float fx = (float)xc;
+  const float rx0 = ik[0] * fx, rx1 = ik[3] * fx, rx2 = ik[6] * fx;
+  const float g = a.gscale[0] * a.inv_count;
+  const float g_ssim = g * 0.85f / 3.f / 9.f, g_l1 = g * 0.15f / 3.f;
+  const float sx_scale = (float)W / (float)(W - 1), sy_scale = (float)H / (float)(H - 1);   // d ix / d u, d iy / d v
+  constexpr int NK = BS_ROWS + 2;
 
 #pragma unroll 1
   for (int f = 0; f < NS; ++f) {
-    __syncthreads();   // previous frame's s_x / s_cf fully consumed; s_cam / s_y visible
-    const float* Pf = s_cam + 9 + f * 12;
     const float* srcb = a.src[f] + (size_t)b * 3 * plane;
+    float P[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) P[e] = a.P[(f * a.B + b) * 12 + e];
     const int sel = a.n_ident + f;
 
-    // ---- 1. re-warp over tile + halo 2 ----
-    for (int pos = tid; pos < B2H * B2W; pos += TD_THREADS) {
-      const int py = pos / B2W, px = pos - py * B2W;
-      const int qy = reflect1(ty0 + py - 2, H), qx = reflect1(tx0 + px - 2, W);
-      const float d = upsample_disp(dispb, a.hs, a.ws, ry, rx, qy, qx);
-      const float depth = fast_rcp(a.min_disp + a.disp_range * d);
-      float pt[3], cz[3];
-      const Tap t = project_tap(s_cam, Pf, depth, qx, qy, W, H, pt, cz);
+    float p_hc[2][9];                                // horizontal coefficient sums of the two previous rows
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s_x[c][py][px] = sample_tap(srcb + (size_t)c * plane, W, t);
-    }
-    __syncthreads();
-
-    // ---- 2. SSIM adjoint coefficients over tile + halo 1 ----
-    for (int pos = tid; pos < B1H * B1W; pos += TD_THREADS) {
-      const int py = pos / B1W, px = pos - py * B1W;
-      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-      bool on = gy >= 0 && gy < H && gx >= 0 && gx < W;
-      if (on) on = a.argmin[(size_t)b * plane + (size_t)gy * W + gx] == sel;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float al = 0.f, be = 0.f, ga = 0.f;
-        if (on) {
-          float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-              const float x = s_x[c][py + dy][px + dx], y = s_y[c][py + dy][px + dx];
-              sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
-            }
-          const float k = 1.f / 9.f;
-          const float mx = sx * k, my = sy * k;
-          const float vx = sxx * k - mx * mx, vy = syy * k - my * my, cxy = sxy * k - mx * my;
-          const float A1 = 2.f * mx * my + TD_SSIM_C1, A2 = 2.f * cxy + TD_SSIM_C2;
-          const float B1 = mx * mx + my * my + TD_SSIM_C1, B2 = vx + vy + TD_SSIM_C2;
-          const float n = A1 * A2, d = B1 * B2;
-          const float invd = fast_rcp(d);
-          const float s = (1.f - n * invd) * 0.5f;
-          if (s >= 0.f && s <= 1.f) {     // clamp passes gradient on the closed interval
-            const float q = n * invd;
-            al = -invd * (my * (A2 - A1) - q * mx * (B2 - B1)) * g_ssim;
-            be = invd * q * B1 * g_ssim;
-            ga = -invd * A1 * g_ssim;
-          }
-        }
-        s_cf[c * 3 + 0][py][px] = al;
-        s_cf[c * 3 + 1][py][px] = be;
-        s_cf[c * 3 + 2][py][px] = ga;
-      }
-    }
-    __syncthreads();
-
-    // ---- 3. gather at the owned pixels, chain to depth and P ----
+    for (int i = 0; i < 9; ++i) p_hc[0][i] = p_hc[1][i] = 0.f;
     float dP[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dP[k] = 0.f;
+    for (int e = 0; e < 12; ++e) dP[e] = 0.f;
+
+    // ---- load pipeline ----
+    // coefficient row k (padded row r = y0-1+k) is consumed in iteration k;
+    // the warp of gradient row q = r-1 is consumed in the same iteration.
+    float dv[4], dv_n[4], ul0, ul1, ul0_n, ul1_n;
+    Tap tap;
+    TapVals tv[3];
+    float yq[3], depth_q, cf_n[9], m_n, mq_n;
+    auto issue_disp = [&](int q, float* d4, float& l0, float& l1) {        // gradient row q (clamped)
+      const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
+      const UpIdx uy = up_index(qc, ratio_y, a.hs);
+      const unsigned o0 = (unsigned)(uy.i0 * a.ws), o1 = (unsigned)(uy.i1 * a.ws);
+      d4[0] = dispb[o0 + (unsigned)ux.i0]; d4[1] = dispb[o0 + (unsigned)ux.i1];
+      d4[2] = dispb[o1 + (unsigned)ux.i0]; d4[3] = dispb[o1 + (unsigned)ux.i1];
+      l0 = uy.l0; l1 = uy.l1;
+    };
+    auto issue_row = [&](int k, const float* d4, float l0, float l1) {
+      const int r = y0 - 1 + k;                      // coefficient row
+      const bool inside = r >= 0 && r < H && col_in;
+      const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+      const unsigned offc = (unsigned)(rc * W + xc);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int oy = oyb + j;
-      const int gy = ty0 + oy, gx = tx0 + ox;
-      if (gy < H && gx < W) {
-        const int my0 = 1 + (gy == 1 ? 1 : 0), my2 = 1 + (gy == H - 2 ? 1 : 0);
-        const int mx0 = 1 + (gx == 1 ? 1 : 0), mx2 = 1 + (gx == W - 2 ? 1 : 0);
-        const bool mine = a.argmin[(size_t)b * plane + (size_t)gy * W + gx] == sel;
-        float gw[3];
-        bool any = false;
+      for (int i = 0; i < 9; ++i) cf_n[i] = cfb[i * plane + offc];
+      m_n = (inside && (int)amb[offc] == sel) ? g_ssim : 0.f;
+      // warp of gradient row q = r - 1
+      const int q = r - 1;
+      const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
+      const unsigned offq = (unsigned)(qc * W + xc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) yq[c] = tgtb[c * plane + offq];
+      mq_n = (q >= 0 && q < H && (int)amb[offq] == sel) ? g_l1 : 0.f;
+      const float dd = l0 * (ux.l0 * d4[0] + ux.l1 * d4[1]) + l1 * (ux.l0 * d4[2] + ux.l1 * d4[3]);
+      depth_q = fast_rcp(a.min_disp + a.disp_range * dd);
+      const float fy = (float)qc;
+      float pt[3], cz[3];
+      tap = project_ray(rx0 + ik[1] * fy + ik[2], rx1 + ik[4] * fy + ik[5], rx2 + ik[7] * fy + ik[8], P, depth_q,
+                        W, H, pt, cz);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tv[c] = load_taps(srcb + c * plane, W, tap);
+    };
+    issue_disp(y0 - 2, dv, ul0, ul1);                // q of k = 0
+    issue_disp(y0 - 1, dv_n, ul0_n, ul1_n);          // q of k = 1
+    issue_row(0, dv, ul0, ul1);
+
+#pragma unroll 1
+    for (int k = 0; k < NK; ++k) {
+      // ---- consume: coefficient row r, warp of row q = r-1 ----
+      float cf[9], xq[3], yv[3], dxi[3], dyi[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cf[i] = cf_n[i] * m_n;
+      const float ex = (float)tap.x0 + 1.f - tap.ix, wx = tap.ix - (float)tap.x0;
+      const float ey = (float)tap.y0 + 1.f - tap.iy, wy = tap.iy - (float)tap.y0;
+      const float mx = tap.gmx * sx_scale, my = tap.gmy * sy_scale;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xq[c] = blend_taps(tv[c], tap);
+        yv[c] = yq[c];
+        const float vnw = tv[c].nw;
+        const float vne = tap.in_e ? tv[c].ne : 0.f;
+        const float vsw = tap.in_s ? tv[c].sw : 0.f;
+        const float vse = (tap.in_e && tap.in_s) ? tv[c].se : 0.f;
+        dxi[c] = (-vnw * ey + vne * ey - vsw * wy + vse * wy) * mx;     // d x_c / d u
+        dyi[c] = (-vnw * ex - vne * wx + vsw * ex + vse * wx) * my;     // d x_c / d v
+      }
+      const float dq = depth_q, ml1 = mq_n;
+      // ---- refill the pipeline (rows beyond the chunk are clamped duplicates, never consumed) ----
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dv[i] = dv_n[i];
+      ul0 = ul0_n; ul1 = ul1_n;
+      issue_disp(y0 + k, dv_n, ul0_n, ul1_n);        // q of k + 2
+      issue_row(k + 1, dv, ul0, ul1);
+
+      // ---- box filter of the coefficient field -> gradient w.r.t. the warped pixel of row q ----
+      const int q = y0 - 2 + k;
+      const float wy0 = (q == 1) ? 2.f : 1.f, wy2 = (q == H - 2) ? 2.f : 1.f;
+      float gw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float hc = (wl * lane_left(cf[i]) + cf[i]) + wr * lane_right(cf[i]);
+        const float G = wy0 * p_hc[0][i] + p_hc[1][i] + wy2 * hc;
+        const int c = i / 3, t = i % 3;
+        gw[c] += (t == 0) ? G : (t == 1 ? G * xq[c] : G * yv[c]);
+        p_hc[0][i] = p_hc[1][i]; p_hc[1][i] = hc;
+      }
+      if (k >= 2 && q < H && col_out) {
+        float du = 0.f, dvv = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          float Ga = 0.f, Gb = 0.f, Gc = 0.f;
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            const float wy = (float)(dy == 0 ? my0 : (dy == 2 ? my2 : 1));
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-              const float w = wy * (float)(dx == 0 ? mx0 : (dx == 2 ? mx2 : 1));
-              Ga += w * s_cf[c * 3 + 0][oy + dy][ox + dx];
-              Gb += w * s_cf[c * 3 + 1][oy + dy][ox + dx];
-              Gc += w * s_cf[c * 3 + 2][oy + dy][ox + dx];
-            }
-          }
-          const float x = s_x[c][oy + 2][ox + 2], y = s_y[c][oy + 2][ox + 2];
-          float v = Ga + Gb * x + Gc * y;
-          if (mine) {
-            const float df = x - y;
-            v += g_l1 * df * fast_rcp(fast_sqrt(df * df + TD_L1_EPS2));
-          }
-          gw[c] = v;
-          any = any || (v != 0.f);
+          const float df = xq[c] - yv[c];
+          const float v = gw[c] + ml1 * df * fast_rcp(fast_sqrt(df * df + TD_L1_EPS2));
+          du += v * dxi[c];
+          dvv += v * dyi[c];
         }
-        if (any) {
-          const float d = upsample_disp(dispb, a.hs, a.ws, ry, rx, gy, gx);
-          const float depth = fast_rcp(a.min_disp + a.disp_range * d);
-          float pt[3], cz[3];
-          const Tap t = project_tap(s_cam, Pf, depth, gx, gy, W, H, pt, cz);
-          float gix = 0.f, giy = 0.f;
-          const float ex = (float)t.x0 + 1.f - t.ix, wx = t.ix - (float)t.x0;
-          const float ey = (float)t.y0 + 1.f - t.iy, wy = t.iy - (float)t.y0;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float* r0 = srcb + (size_t)c * plane + (size_t)t.y0 * W;
-            const float* r1 = srcb + (size_t)c * plane + (size_t)t.y1 * W;
-            const float l_nw = r0[t.x0], l_ne = r0[t.x1], l_sw = r1[t.x0], l_se = r1[t.x1];
-            const float vnw = l_nw;
-            const float vne = t.in_e ? l_ne : 0.f;
-            const float vsw = t.in_s ? l_sw : 0.f;
-            const float vse = (t.in_e && t.in_s) ? l_se : 0.f;
-            gix += gw[c] * (-vnw * ey + vne * ey - vsw * wy + vse * wy);
-            giy += gw[c] * (-vnw * ex - vne * wx + vsw * ex + vse * wx);
-          }
-          // grid_sampler unnormalise (W/2) * clip multiplier, then (u/(W-1) - 0.5) * 2
-          const float du = gix * t.gmx * ((float)W * 0.5f) * 2.f / (float)(W - 1);
-          const float dv = giy * t.gmy * ((float)H * 0.5f) * 2.f / (float)(H - 1);
-          const float iz = fast_rcp(cz[2]);
-          const float dc0 = du * iz, dc1 = dv * iz;
-          const float dc2 = -(du * cz[0] + dv * cz[1]) * iz * iz;
-          dP[0] += dc0 * pt[0]; dP[1] += dc0 * pt[1]; dP[2] += dc0 * pt[2]; dP[3] += dc0;
-          dP[4] += dc1 * pt[0]; dP[5] += dc1 * pt[1]; dP[6] += dc1 * pt[2]; dP[7] += dc1;
-          dP[8] += dc2 * pt[0]; dP[9] += dc2 * pt[1]; dP[10] += dc2 * pt[2]; dP[11] += dc2;
-          // d/d depth: point = depth * ray, ray = point / depth
-          const float dX = dc0 * Pf[0] + dc1 * Pf[4] + dc2 * Pf[8];
-          const float dY = dc0 * Pf[1] + dc1 * Pf[5] + dc2 * Pf[9];
-          const float dZ = dc0 * Pf[2] + dc1 * Pf[6] + dc2 * Pf[10];
-          const float fx = (float)gx, fy = (float)gy;
-          const float r0 = s_cam[0] * fx + s_cam[1] * fy + s_cam[2];
-          const float r1 = s_cam[3] * fx + s_cam[4] * fy + s_cam[5];
-          const float r2 = s_cam[6] * fx + s_cam[7] * fy + s_cam[8];
-          const float dD = dX * r0 + dY * r1 + dZ * r2;
-          dup[j] += dD * (-a.disp_range * depth * depth);
-        }
+        const float fyq = (float)q;
+        const float r0 = rx0 + ik[1] * fyq + ik[2], r1 = rx1 + ik[4] * fyq + ik[5], r2 = rx2 + ik[7] * fyq + ik[8];
+        const float X = dq * r0, Y = dq * r1, Z = dq * r2;
+        const float c0 = P[0] * X + P[1] * Y + P[2] * Z + P[3];
+        const float c1 = P[4] * X + P[5] * Y + P[6] * Z + P[7];
+        const float z = P[8] * X + P[9] * Y + P[10] * Z + P[11] + 1e-7f;
+        const float iz = fast_rcp(z);
+        const float dc0 = du * iz, dc1 = dvv * iz, dc2 = -(du * c0 + dvv * c1) * iz * iz;
+        dP[0] += dc0 * X; dP[1] += dc0 * Y; dP[2] += dc0 * Z; dP[3] += dc0;
+        dP[4] += dc1 * X; dP[5] += dc1 * Y; dP[6] += dc1 * Z; dP[7] += dc1;
+        dP[8] += dc2 * X; dP[9] += dc2 * Y; dP[10] += dc2 * Z; dP[11] += dc2;
+        const float dX = dc0 * P[0] + dc1 * P[4] + dc2 * P[8];
+        const float dY = dc0 * P[1] + dc1 * P[5] + dc2 * P[9];
+        const float dZ = dc0 * P[2] + dc1 * P[6] + dc2 * P[10];
+        const float dD = dX * r0 + dY * r1 + dZ * r2;
+        const float contrib = dD * (-a.disp_range * dq * dq);
+        float* dst = dupb + (unsigned)(q * W + x);
+        if (f == 0) *dst = contrib; else *dst += contrib;
       }
     }
-
-    // block-reduce dP for this frame
 #pragma unroll
-    for (int k = 0; k < 12; ++k) dP[k] = wave_sum(dP[k]);
-    const int lane = tid & 63, wid = tid >> 6;
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 12; ++k) s_red[wid][k] = dP[k];
-    }
-    __syncthreads();
-    if (tid < 12) {
-      const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      a.dP_partial[blk * (NS * 12) + f * 12 + tid] =
-          (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    for (int e = 0; e < 12; ++e) {
+      const float tot = wave_sum(dP[e]);
+      if (lane == 0) a.dP_partial[(size_t)task * (NS * 12) + f * 12 + e] = tot;
     }
   }
+}
 
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int gy = ty0 + oyb + j, gx = tx0 + ox;
-    if (gy < H && gx < W) a.d_up[(size_t)b * plane + (size_t)gy * W + gx] = dup[j];
-  }
+static int bwd_tasks(int B, int H, int W, int* nstrips, int* nchunks) {
+  *nstrips = (W + BS_COLS - 1) / BS_COLS;
+  *nchunks = (H + BS_ROWS - 1) / BS_ROWS;
+  return B * (*nstrips) * (*nchunks);
 }
 
 template <int NS>
 static int run_bwd(const float* tgt, const float* const* src, const float* disp, const float* P,
-                   const float* invK, const uint8_t* argmin, int automask, const float* gscale,
+                   const float* invK, const uint8_t* argmin, const float* coef, int automask, const float* gscale,
                    float inv_count, int B, int H, int W, int hs, int ws, float min_depth,
                    float max_depth, float* d_up, float* dP_partial, hipStream_t st) {
   PhotoBwdArgs<NS> a;
   a.tgt = tgt;
   for (int i = 0; i < NS; ++i) a.src[i] = src[i];
-  a.disp = disp; a.P = P; a.invK = invK; a.argmin = argmin; a.gscale = gscale;
+  a.disp = disp; a.P = P; a.invK = invK; a.argmin = argmin; a.coef = coef; a.gscale = gscale;
   a.d_up = d_up; a.dP_partial = dP_partial;
   a.B = B; a.H = H; a.W = W; a.hs = hs; a.ws = ws;
   a.n_ident = automask ? NS : 0;
@@ -252,8 +231,10 @@ static int run_bwd(const float* tgt, const float* const* src, const float* disp,
   const double lo = 1.0 / (double)max_depth, hi = 1.0 / (double)min_depth;
   a.min_disp = (float)lo;
   a.disp_range = (float)(hi - lo);
-  dim3 grid((W + BT_W - 1) / BT_W, (H + BT_H - 1) / BT_H, B);
-  hipLaunchKernelGGL((photo_bwd_kernel<NS>), grid, dim3(TD_THREADS), 0, st, a);
+  a.ntasks = bwd_tasks(B, H, W, &a.nstrips, &a.nchunks);
+  const int blocks = (a.ntasks + BS_WAVES - 1) / BS_WAVES;
+  a.blocks_per_xcd = (blocks + 7) / 8;
+  hipLaunchKernelGGL((photo_bwd_kernel<NS>), dim3(a.blocks_per_xcd * 8), dim3(BS_WAVES * 64), 0, st, a);
   return record_launch_error(hipGetLastError(), "td_photo_bwd");
 }
 
@@ -317,34 +298,37 @@ __global__ __launch_bounds__(TD_THREADS) void upsample_adjoint_kernel(
 }  // namespace td
 
 extern "C" int td_photo_bwd(const float* tgt, const float* const* src, int n_src, const float* disp,
-                            const float* P, const float* invK, const uint8_t* argmin, int automask,
-                            const float* gscale, float inv_count, int B, int H, int W, int hs, int ws,
+                            const float* P, const float* invK, const uint8_t* argmin, const float* coef,
+                            int automask, const float* gscale, float inv_count, int B, int H, int W, int hs, int ws,
                             float min_depth, float max_depth, float* d_up, float* dP_partial,
                             td_stream_t stream) {
-  if (!tgt || !src || !disp || !P || !invK || !argmin || !gscale || !d_up || !dP_partial) return TD_ERR_BAD_ARG;
+  if (!tgt || !src || !disp || !P || !invK || !argmin || !coef || !gscale || !d_up || !dP_partial) return TD_ERR_BAD_ARG;
   if (n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W) return TD_ERR_BAD_ARG;
   if (!(min_depth > 0.f) || !(max_depth > min_depth)) return TD_ERR_BAD_ARG;
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
-  if (H < 3 || W < 3) return TD_ERR_UNSUPPORTED;
+  if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   switch (n_src) {
-    case 1: return td::run_bwd<1>(tgt, src, disp, P, invK, argmin, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
-    case 2: return td::run_bwd<2>(tgt, src, disp, P, invK, argmin, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
-    case 3: return td::run_bwd<3>(tgt, src, disp, P, invK, argmin, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
-    case 4: return td::run_bwd<4>(tgt, src, disp, P, invK, argmin, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 1: return td::run_bwd<1>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 2: return td::run_bwd<2>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 3: return td::run_bwd<3>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 4: return td::run_bwd<4>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
   }
   return TD_ERR_BAD_ARG;
 }
 
 extern "C" int td_photo_bwd_num_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return B * ((H + td::BT_H - 1) / td::BT_H) * ((W + td::BT_W - 1) / td::BT_W);
+  int ns, nc;
+  return td::bwd_tasks(B, H, W, &ns, &nc);
 }
 
 extern "C" int td_reduce_dP(const float* dP_partial, int n_src, int B, int H, int W, float* dP,
                             td_stream_t stream) {
   if (!dP_partial || !dP || n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || H <= 0 || W <= 0) return TD_ERR_BAD_ARG;
-  const int bps = ((H + td::BT_H - 1) / td::BT_H) * ((W + td::BT_W - 1) / td::BT_W);
+  int ns, nc;
+  td::bwd_tasks(1, H, W, &ns, &nc);
+  const int bps = ns * nc;
   hipLaunchKernelGGL(td::reduce_dP_kernel, dim3(n_src * 12, B), dim3(64), 0, (hipStream_t)stream,
                      dP_partial, n_src, B, bps, dP);
   return td::record_launch_error(hipGetLastError(), "td_reduce_dP");

@@ -31,6 +31,7 @@ struct PhotoFwdArgs {
   float* min_map;
   float* partial;
   float* idloss_out;   // identity mode only
+  float* coef;         // [B,9,H,W] SSIM-adjoint coefficients of the selected warped frame (nullable)
   int B, H, W, hs, ws;
   int nstrips, nchunks, ntasks, blocks_per_xcd;
   float min_disp, disp_range;
@@ -60,7 +61,7 @@ struct DispTaps {
 
 // MODE: 0 = identity-term kernel, 1 = warped terms only, 2 = + auto-mask, 3 = + auto-mask noise.
 // KEEP: also write the warped sources.
-template <int NS, int MODE, bool KEEP>
+template <int NS, int MODE, bool KEEP, bool COEF>
 __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwdArgs<NS> a) {
   constexpr bool IDENT = MODE == 0;
   const int lane = threadIdx.x & 63;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
         for (int c = 0; c < 3; ++c) a.warped[(((size_t)f * a.B + b) * 3 + c) * plane + (unsigned)(r * W + x)] = xw[f][c];
     }
     float ss[NS], l1[NS];
+    float cfs[COEF ? NS : 1][9];                     // (alpha, beta, gamma) per channel of every warped frame
 #pragma unroll
     for (int f = 0; f < NS; ++f) { ss[f] = 0.f; l1[f] = 0.f; }
 #pragma unroll
@@ -205,7 +207,13 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
           const float sx = p_hx[0][f][c] + p_hx[1][f][c] + hx[f];
           const float sxx = p_hxx[0][f][c] + p_hxx[1][f][c] + hxx[f];
           const float sxy = p_hxy[0][f][c] + p_hxy[1][f][c] + hxy[f];
-          ss[f] += ssim_from_sums(sx, sy, sxx, syy, sxy);
+          if (COEF) {
+            float al, be, ga;
+            ss[f] += ssim_with_adjoint(sx, sy, sxx, syy, sxy, al, be, ga);
+            cfs[COEF ? f : 0][c * 3 + 0] = al; cfs[COEF ? f : 0][c * 3 + 1] = be; cfs[COEF ? f : 0][c * 3 + 2] = ga;
+          } else {
+            ss[f] += ssim_from_sums(sx, sy, sxx, syy, sxy);
+          }
           const float df = c_y[c] - c_x[f][c];
           l1[f] += fast_sqrt(df * df + TD_L1_EPS2);
         }
@@ -248,6 +256,15 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
         a.argmin[(size_t)b * plane + pix] = (uint8_t)idx;
         if (a.min_map != nullptr) a.min_map[(size_t)b * plane + pix] = best;
         acc += best;
+        if (COEF) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            float v = 0.f;
+#pragma unroll
+            for (int f = 0; f < NS; ++f) v = (idx == base + f) ? cfs[COEF ? f : 0][i] : v;
+            a.coef[((size_t)b * 9 + i) * plane + pix] = v;
+          }
+        }
       }
     }
   };
@@ -294,12 +311,12 @@ static int fwd_tasks(int B, int H, int W, int* nstrips, int* nchunks) {
   return B * (*nstrips) * (*nchunks);
 }
 
-template <int NS, int MODE, bool KEEP>
+template <int NS, int MODE, bool KEEP, bool COEF>
 static int launch_fwd(PhotoFwdArgs<NS>& a, hipStream_t st) {
   a.ntasks = fwd_tasks(a.B, a.H, a.W, &a.nstrips, &a.nchunks);
   const int blocks = (a.ntasks + FS_WAVES - 1) / FS_WAVES;
   a.blocks_per_xcd = (blocks + 7) / 8;
-  hipLaunchKernelGGL((photo_fwd_kernel<NS, MODE, KEEP>), dim3(a.blocks_per_xcd * 8), dim3(FS_WAVES * 64), 0, st, a);
+  hipLaunchKernelGGL((photo_fwd_kernel<NS, MODE, KEEP, COEF>), dim3(a.blocks_per_xcd * 8), dim3(FS_WAVES * 64), 0, st, a);
   return record_launch_error(hipGetLastError(), MODE == 0 ? "td_photo_identity" : "td_photo_fwd");
 }
 
@@ -307,27 +324,42 @@ template <int NS>
 static int run_fwd(const float* tgt, const float* const* src, const float* disp, const float* P,
                    const float* invK, const float* idloss, const float* noise, int B, int H, int W,
                    int hs, int ws, float min_depth, float max_depth, uint8_t* argmin, float* warped,
-                   float* min_map, float* partial, float* idloss_out, bool ident, hipStream_t st) {
+                   float* min_map, float* partial, float* idloss_out, float* coef, bool ident, hipStream_t st) {
   PhotoFwdArgs<NS> a;
   a.tgt = tgt;
   for (int i = 0; i < NS; ++i) a.src[i] = src[i];
   a.disp = disp; a.P = P; a.invK = invK; a.idloss = idloss; a.noise = noise;
   a.argmin = argmin; a.warped = warped; a.min_map = min_map; a.partial = partial;
   a.idloss_out = idloss_out;
+  a.coef = coef;
   a.B = B; a.H = H; a.W = W; a.hs = hs; a.ws = ws;
   const double lo = 1.0 / (double)max_depth, hi = 1.0 / (double)min_depth;
   a.min_disp = (float)lo;
   a.disp_range = (float)(hi - lo);
-  if (ident) return launch_fwd<NS, 0, false>(a, st);
+  if (ident) return launch_fwd<NS, 0, false, false>(a, st);
   const int mode = idloss == nullptr ? 1 : (noise == nullptr ? 2 : 3);
   const bool keep = warped != nullptr;
+  if (a.coef != nullptr && !keep) {        // training step: emit the adjoint coefficients
+    switch (mode) {
+      case 1: return launch_fwd<NS, 1, false, true>(a, st);
+      case 2: return launch_fwd<NS, 2, false, true>(a, st);
+      default: return launch_fwd<NS, 3, false, true>(a, st);
+    }
+  }
+  if (a.coef != nullptr) {
+    switch (mode) {
+      case 1: return launch_fwd<NS, 1, true, true>(a, st);
+      case 2: return launch_fwd<NS, 2, true, true>(a, st);
+      default: return launch_fwd<NS, 3, true, true>(a, st);
+    }
+  }
   switch (mode * 2 + (keep ? 1 : 0)) {
-    case 2: return launch_fwd<NS, 1, false>(a, st);
-    case 3: return launch_fwd<NS, 1, true>(a, st);
-    case 4: return launch_fwd<NS, 2, false>(a, st);
-    case 5: return launch_fwd<NS, 2, true>(a, st);
-    case 6: return launch_fwd<NS, 3, false>(a, st);
-    default: return launch_fwd<NS, 3, true>(a, st);
+    case 2: return launch_fwd<NS, 1, false, false>(a, st);
+    case 3: return launch_fwd<NS, 1, true, false>(a, st);
+    case 4: return launch_fwd<NS, 2, false, false>(a, st);
+    case 5: return launch_fwd<NS, 2, true, false>(a, st);
+    case 6: return launch_fwd<NS, 3, false, false>(a, st);
+    default: return launch_fwd<NS, 3, true, false>(a, st);
   }
 }
 
@@ -343,13 +375,13 @@ static int dispatch_fwd(const float* tgt, const float* const* src, int n_src, co
                         const float* P, const float* invK, const float* idloss, const float* noise,
                         int B, int H, int W, int hs, int ws, float min_depth, float max_depth,
                         uint8_t* argmin, float* warped, float* min_map, float* partial,
-                        float* idloss_out, bool ident, td_stream_t stream) {
+                        float* idloss_out, float* coef, bool ident, td_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   switch (n_src) {
-    case 1: return td::run_fwd<1>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, ident, st);
-    case 2: return td::run_fwd<2>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, ident, st);
-    case 3: return td::run_fwd<3>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, ident, st);
-    case 4: return td::run_fwd<4>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, ident, st);
+    case 1: return td::run_fwd<1>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
+    case 2: return td::run_fwd<2>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
+    case 3: return td::run_fwd<3>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
+    case 4: return td::run_fwd<4>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
   }
   return TD_ERR_BAD_ARG;
 }
@@ -360,13 +392,13 @@ extern "C" int td_photo_identity(const float* tgt, const float* const* src, int 
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
   if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   return dispatch_fwd(tgt, src, n_src, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, 1, 1,
-                      0.1f, 100.f, nullptr, nullptr, nullptr, nullptr, idloss, true, stream);
+                      0.1f, 100.f, nullptr, nullptr, nullptr, nullptr, idloss, nullptr, true, stream);
 }
 
 extern "C" int td_photo_fwd(const float* tgt, const float* const* src, int n_src, const float* disp,
                             const float* P, const float* invK, const float* idloss, const float* noise,
                             int B, int H, int W, int hs, int ws, float min_depth, float max_depth,
-                            uint8_t* argmin, float* warped, float* min_map, float* partial,
+                            uint8_t* argmin, float* warped, float* min_map, float* partial, float* coef,
                             td_stream_t stream) {
   if (!tgt || !src || !disp || !P || !invK || !argmin || !partial) return TD_ERR_BAD_ARG;
   if (n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W) return TD_ERR_BAD_ARG;
@@ -374,5 +406,5 @@ extern "C" int td_photo_fwd(const float* tgt, const float* const* src, int n_src
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
   if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   return dispatch_fwd(tgt, src, n_src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth,
-                      max_depth, argmin, warped, min_map, partial, nullptr, false, stream);
+                      max_depth, argmin, warped, min_map, partial, nullptr, coef, false, stream);
 }

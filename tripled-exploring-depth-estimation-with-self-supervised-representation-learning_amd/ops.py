@@ -58,15 +58,18 @@ class _PhotometricScaleLoss(torch.autograd.Function):
         partial = torch.empty(nblk, device=dev, dtype=torch.float32)
         warped = torch.empty(n_src, B, 3, H, W, device=dev, dtype=torch.float32) if keep_warped else None
         loss = torch.empty(1, device=dev, dtype=torch.float32)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        coef = torch.empty(B, 9, H, W, device=dev, dtype=torch.float32) if need_grad else None
         st = native.stream()
         native.check(lib.td_photo_fwd(native.ptr(tgt), native.ptr_array(srcs), n_src, native.ptr(disp),
                                       native.ptr(P), native.ptr(invK), native.ptr(idloss), native.ptr(noise),
                                       B, H, W, hs, ws, float(min_depth), float(max_depth),
-                                      native.ptr(argmin), native.ptr(warped), None, native.ptr(partial), st),
+                                      native.ptr(argmin), native.ptr(warped), None, native.ptr(partial),
+                                      native.ptr(coef), st),
                      "td_photo_fwd")
         inv_count = 1.0 / (float(B) * H * W * n_scales)
         native.check(lib.td_sum_scaled(native.ptr(partial), nblk, inv_count, native.ptr(loss), st), "td_sum_scaled")
-        ctx.save_for_backward(disp, P, tgt, invK, argmin, *srcs)
+        ctx.save_for_backward(disp, P, tgt, invK, argmin, coef if coef is not None else argmin, *srcs)
         ctx.meta = (min_depth, max_depth, inv_count, idloss is not None, n_src)
         ctx.mark_non_differentiable(argmin)
         if keep_warped:
@@ -77,7 +80,7 @@ class _PhotometricScaleLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_argmin, _g_warped):
         lib = native.load()
-        disp, P, tgt, invK, argmin, *srcs = ctx.saved_tensors
+        disp, P, tgt, invK, argmin, coef, *srcs = ctx.saved_tensors
         min_depth, max_depth, inv_count, automask, n_src = ctx.meta
         B, _, H, W = tgt.shape
         hs, ws = disp.shape[2], disp.shape[3]
@@ -88,8 +91,8 @@ class _PhotometricScaleLoss(torch.autograd.Function):
         dP_part = torch.empty(nblk, n_src * 12, device=dev, dtype=torch.float32)
         st = native.stream()
         native.check(lib.td_photo_bwd(native.ptr(tgt), native.ptr_array(srcs), n_src, native.ptr(disp),
-                                      native.ptr(P), native.ptr(invK), native.ptr(argmin), int(automask),
-                                      native.ptr(g), inv_count, B, H, W, hs, ws, float(min_depth),
+                                      native.ptr(P), native.ptr(invK), native.ptr(argmin), native.ptr(coef),
+                                      int(automask), native.ptr(g), inv_count, B, H, W, hs, ws, float(min_depth),
                                       float(max_depth), native.ptr(d_up), native.ptr(dP_part), st),
                      "td_photo_bwd")
         d_disp = torch.empty_like(disp)
