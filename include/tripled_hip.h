@@ -220,6 +220,15 @@ int td_recon_fwd(const float* x, const float* y, const float* hole, int B, int h
 int td_recon_bwd(const float* x, const float* y, const float* hole, const float* gscale, int B, int h,
                  int w, float* dx, td_stream_t stream);
 
+/*
+ * nn.ReflectionPad2d(1) in front of every decoder Conv3x3 (mono/model/mono_fm_joint/layers.py:171-184) on
+ * channels-last activations: in [N,H,W,C] -> out [N,H+2,W+2,C]; the backward is the gather-form adjoint
+ * (grad_out [N,H+2,W+2,C] -> grad_in [N,H,W,C]).  C % 8 == 0, H, W >= 2.
+ */
+int td_reflpad1_fwd(const void* in, int dtype, int N, int H, int W, int C, void* out, td_stream_t stream);
+int td_reflpad1_bwd(const void* grad_out, int dtype, int N, int H, int W, int C, void* grad_in,
+                    td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,10 +271,15 @@ class Conv3x3(nn.Module):
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
+        self.use_refl = use_refl
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x):
+        if self.use_refl and x.is_cuda and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] >= 2 and x.shape[3] >= 2:
+            from tripled_amd import ops          # gather-form pad / adjoint (ATen's backward uses atomics)
+            return self.conv(ops.reflpad1(x))
         return self.conv(self.pad(x))
 
 

@@ -44,6 +44,8 @@ SIGNATURES = {
     "td_recon_num_tasks": (_I, [_I, _I, _I]),
     "td_recon_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "td_recon_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    "td_reflpad1_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "td_reflpad1_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
 }
 
 DTYPE_CODES = {torch.float32: 0, torch.bfloat16: 1}

@@ -303,3 +303,37 @@ def masked_reconstruction_sum(pred, target, hole):
         raise native.NativeLibraryError("masked_reconstruction_sum needs h, w >= 3")
     pred = pred.float().contiguous()          # (channels-last bf16 decoder output -> planar f32)
     return _ReconSum.apply(pred, _f32c(target.detach()), _f32c(hole.detach()))
+
+
+class _ReflPad1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = native.load()
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, H + 2, W + 2), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_reflpad1_fwd(_raw(x), native.DTYPE_CODES[x.dtype], N, H, W, C, _raw(out), native.stream()),
+                     "td_reflpad1_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        N, C, Ho, Wo = g.shape
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty((N, C, Ho - 2, Wo - 2), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_reflpad1_bwd(_raw(g), native.DTYPE_CODES[g.dtype], N, Ho - 2, Wo - 2, C, _raw(gin),
+                                         native.stream()), "td_reflpad1_bwd")
+        return gin
+
+
+def reflpad1_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 8 == 0
+            and x.shape[2] >= 2 and x.shape[3] >= 2 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def reflpad1(x):
+    """nn.ReflectionPad2d(1) on a channels_last HIP tensor (reference: layers.py:171-184)."""
+    if not reflpad1_supported(x):
+        raise native.NativeLibraryError("reflpad1 needs a channels_last f32/bf16 HIP tensor with C % 8 == 0")
+    return _ReflPad1.apply(x)
