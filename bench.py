@@ -82,8 +82,9 @@ class TrainStep:
         self.params = [p for p in inner.parameters() if p.requires_grad]
         ocfg = dict(cfg.optimizer)
         assert ocfg.pop("type") == "Adam"
-        self.optimizer = torch.optim.Adam(self.params, capturable=torch.cuda.is_available() and batch["K"].is_cuda,
-                                          foreach=True, **ocfg)
+        on_gpu = batch["K"].is_cuda
+        # fused multi-tensor Adam on the GPU (same update rule as torch.optim.Adam(lr, weight_decay=0))
+        self.optimizer = torch.optim.Adam(self.params, capturable=on_gpu, fused=on_gpu, **ocfg)
         clip = cfg.optimizer_config.get("grad_clip", None)
         self.max_norm = clip["max_norm"] if clip else None
         self.reducer = getattr(model, "reducer", None)

@@ -229,6 +229,32 @@ int td_reflpad1_fwd(const void* in, int dtype, int N, int H, int W, int C, void*
 int td_reflpad1_bwd(const void* grad_out, int dtype, int N, int H, int W, int C, void* grad_in,
                     td_stream_t stream);
 
+/*
+ * Feature-metric term: generate_features_pred (mono/model/mono_fm_joint/net.py:196-223) +
+ * compute_perceptional_loss (:63-65) + min over source frames (mono_fm_joint_inpaint/net.py:58-70), fused.
+ *   tgt, src[i]  [B,h,w,C] channels-last feature maps (C % 64 == 0; dtype f32 or bf16); n_src <= 2
+ *   disp         [B,1,hs,ws]; P [n_src,B,3,4] and invK [B,4,4] at FEATURE resolution (K rows 0,1 halved)
+ *   argmin       [B,h,w] uint8 (out: which source frame gives the minimum)
+ *   partial      [td_featwarp_num_blocks] per-block sums of min_f mean_c sqrt((tgt - warp_f)^2 + 1e-6)
+ * Backward (gradient of gscale[0] * inv_count * sum(partial)):
+ *   d_tgt [B,h,w,C] (feature dtype), d_src[i] [B,h,w,C] f32 -- MUST be zero-filled by the caller, the
+ *   scatter accumulates with atomics --, d_up [B,h,w] (w.r.t. the up-sampled disparity; td_upsample_adjoint),
+ *   dP_partial [td_featwarp_num_blocks, n_src*12] (td_reduce_partials with blocks_per_sample =
+ *   td_featwarp_num_blocks / B).
+ */
+int td_featwarp_num_blocks(int B, int h, int w);
+int td_featwarp_fwd(const void* tgt, const void* const* src, int n_src, int dtype, const float* disp,
+                    const float* P, const float* invK, int B, int h, int w, int C, int hs, int ws,
+                    float min_depth, float max_depth, uint8_t* argmin, float* partial, td_stream_t stream);
+int td_featwarp_bwd(const void* tgt, const void* const* src, int n_src, int dtype, const float* disp,
+                    const float* P, const float* invK, const uint8_t* argmin, const float* gscale,
+                    float inv_count, int B, int h, int w, int C, int hs, int ws, float min_depth,
+                    float max_depth, void* d_tgt, float* const* d_src, float* d_up, float* dP_partial,
+                    td_stream_t stream);
+/* dP[i,b,:] = sum over the blocks_per_sample consecutive rows of partial[., n_src*12] that belong to sample b. */
+int td_reduce_partials(const float* partial, int n_src, int B, int blocks_per_sample, float* dP,
+                       td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

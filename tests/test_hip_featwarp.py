@@ -1,0 +1,63 @@
+"""GPU parity: fused feature-metric kernels vs the unfused torch composition (forward + all gradients)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import geometry, photometric  # noqa: E402
+from tests.util import kitti_K, random_poses, rel_err, smooth_image  # noqa: E402
+
+
+def _reference(tgt_f, src_fs, disp, K, invK, Ts, h, w):
+    up = F.interpolate(disp, [h, w], mode="bilinear", align_corners=False)
+    _, depth = geometry.disp_to_depth(up, 0.1, 100.0)
+    pts = geometry.backproject(depth, invK)
+    cands = []
+    for s, T in zip(src_fs, Ts):
+        grid = geometry.project(pts, K, T, h, w)
+        warped = F.grid_sample(s, grid, mode="bilinear", padding_mode="border", align_corners=False)
+        cands.append(photometric.perceptional_loss(tgt_f, warped))
+    vals, idx = torch.min(torch.cat(cands, 1), dim=1)
+    return vals.mean(), idx
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,h,w,hs,ws", [(2, 64, 12, 20, 12, 20), (1, 64, 9, 37, 9, 37), (2, 128, 6, 10, 3, 5)])
+def test_feature_metric(dtype, B, C, h, w, hs, ws):
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    g = torch.Generator().manual_seed(2)
+    base = torch.randn(B, C, h + 4, w + 4, generator=g)
+    base = F.avg_pool2d(base, 3, 1, 1)                      # smooth features so the warp gradient is meaningful
+    tgt = base[:, :, 2:2 + h, 2:2 + w].contiguous()
+    srcs = [base[:, :, 2:2 + h, 1:1 + w].contiguous(), base[:, :, 3:3 + h, 2:2 + w].contiguous()]
+    K, invK = kitti_K(B, h, w)
+    Ts = random_poses(g, B, rot=0.005, trans=0.05)
+    disp = (0.2 + 0.6 * smooth_image(g, B, 1, max(hs, 8), max(ws, 8))[:, :, :hs, :ws]).contiguous()
+    cl = lambda t: t.to(dtype).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    tg, sg = cl(tgt), [cl(s) for s in srcs]
+    dg = disp.cuda().requires_grad_(True)
+    Tg = [T.cuda().requires_grad_(True) for T in Ts]
+    P = torch.stack([torch.matmul(K.cuda(), T)[:, :3, :] for T in Tg], 0)
+    loss, idx = ops.feature_warp_min_loss(tg, sg, dg, P, invK.cuda(), 0.1, 100.0)
+    (loss * 2.0).backward()
+
+    ref_in = lambda t: t.to(dtype).float().clone().requires_grad_(True)   # reference computes on .float()
+    tr, sr = ref_in(tgt), [ref_in(s) for s in srcs]
+    dr = disp.clone().requires_grad_(True)
+    Tr = [T.clone().requires_grad_(True) for T in Ts]
+    ref, ridx = _reference(tr, sr, dr, K, invK, Tr, h, w)
+    (ref * 2.0).backward()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert abs(float(loss) - float(ref)) < tol * max(1e-3, abs(float(ref)))
+    agree = (idx.cpu().long() == ridx).float().mean()
+    assert agree > 0.99
+    # the robust-L1 slope d/dx sqrt(x^2 + 1e-6) changes by 1e3 per unit near 0: ~3e-6 warp rounding -> ~3e-3
+    gt = 1e-2 if dtype == torch.float32 else 3e-2
+    assert rel_err(tg.grad.float(), tr.grad) < gt
+    for a, r in zip(sg, sr):
+        assert rel_err(a.grad.float(), r.grad) < gt
+    assert rel_err(dg.grad, dr.grad) < max(gt, 5e-3)
+    for a, r in zip(Tg, Tr):
+        assert rel_err(a.grad, r.grad) < max(gt, 5e-3)

@@ -334,6 +334,14 @@ extern "C" int td_reduce_dP(const float* dP_partial, int n_src, int B, int H, in
   return td::record_launch_error(hipGetLastError(), "td_reduce_dP");
 }
 
+extern "C" int td_reduce_partials(const float* partial, int n_src, int B, int blocks_per_sample, float* dP,
+                                  td_stream_t stream) {
+  if (!partial || !dP || n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || blocks_per_sample <= 0) return TD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(td::reduce_dP_kernel, dim3(n_src * 12, B), dim3(64), 0, (hipStream_t)stream, partial, n_src, B,
+                     blocks_per_sample, dP);
+  return td::record_launch_error(hipGetLastError(), "td_reduce_partials");
+}
+
 extern "C" int td_upsample_adjoint(const float* d_up, int B, int H, int W, int hs, int ws,
                                    float* d_disp, int accumulate, td_stream_t stream) {
   if (!d_up || !d_disp || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W) return TD_ERR_BAD_ARG;

@@ -65,7 +65,11 @@ def build_optimizer(model, optimizer_cfg):
     optimizer_cfg = dict(optimizer_cfg)
     paramwise = optimizer_cfg.pop("paramwise_options", None)
     if paramwise is None:
-        return obj_from_dict(optimizer_cfg, torch.optim, dict(params=model.parameters()))
+        extra = dict(params=model.parameters())
+        first = next(model.parameters(), None)
+        if optimizer_cfg.get("type") in ("Adam", "AdamW") and first is not None and first.is_cuda:
+            extra["fused"] = True        # one multi-tensor kernel per step instead of ~10 tiny kernels per parameter
+        return obj_from_dict(optimizer_cfg, torch.optim, extra)
     assert isinstance(paramwise, dict)
     base_lr = optimizer_cfg["lr"]
     base_wd = optimizer_cfg.get("weight_decay", None)

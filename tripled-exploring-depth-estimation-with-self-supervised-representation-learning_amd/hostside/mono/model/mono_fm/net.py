@@ -4,7 +4,7 @@ term is evaluated per scale with weight perception_weight / n_scales."""
 import torch
 
 from ..registry import MONO
-from ..networks import DepthDecoder, DepthEncoder, Encoder, PoseDecoder, PoseEncoder
+from ..networks import DepthDecoder, DepthEncoder, Encoder, PoseDecoder, PoseEncoder, install_counter_hook
 from ..mono_fm_joint.layers import SSIM, Backproject, Project
 from ..mono_fm_joint.net import mono_fm_joint
 
@@ -42,6 +42,7 @@ class mono_fm(mono_fm_joint):
         self.project = Project(self.opt.imgs_per_gpu, self.opt.height, self.opt.width)
         self._loss_backend = None
         self._noise_fn = None
+        install_counter_hook(self)
 
     def forward(self, inputs):
         outputs = self.DepthDecoder(self.DepthEncoder(inputs["color_aug", 0, 0]))

@@ -8,7 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import MONO
-from ..networks import DepthEncoder, DepthDecoder, PoseEncoder, PoseDecoder, Encoder, Decoder
+from ..networks import DepthEncoder, DepthDecoder, PoseEncoder, PoseDecoder, Encoder, Decoder, install_counter_hook
 from .layers import SSIM, Backproject, Project
 from .. import hotpath
 
@@ -32,6 +32,7 @@ class mono_fm_joint(nn.Module):
         self.project = Project(self.opt.imgs_per_gpu, self.opt.height, self.opt.width)
         self._loss_backend = None
         self._noise_fn = None
+        install_counter_hook(self)
 
     # ------------------------------------------------------------------ plumbing
     def set_loss_backend(self, backend):

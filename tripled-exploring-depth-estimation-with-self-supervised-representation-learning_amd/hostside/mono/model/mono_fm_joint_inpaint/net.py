@@ -49,6 +49,24 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             return outputs, self.compute_losses(inputs, outputs, features)
         return outputs
 
+    def _fused_feature_metric(self, inputs, outputs, tgt_f):
+        """Feature-metric term through the fused HIP kernel (no warped feature maps are materialised);
+        None when the inputs are not channels-last HIP tensors or the caller wants the warped features."""
+        opt = self.opt
+        if not tgt_f.is_cuda or opt.get("keep_warped_images", False) or "s" in opt.frame_ids:
+            return None
+        from tripled_amd import ops
+        src_f = [self._source_features(inputs[("color", f, 0)]) for f in opt.frame_ids[1:]]
+        if not ops.featwarp_supported(tgt_f, src_f):
+            return None
+        K = inputs["K"].float().clone()
+        K[:, 0:2, :] = K[:, 0:2, :] / 2
+        inv_K = inputs["inv_K"].float().clone()
+        inv_K[:, :, 0:2] = inv_K[:, :, 0:2] * 2          # see generate_features_pred
+        P = torch.stack([torch.matmul(K, outputs[("cam_T_cam", 0, f)].float())[:, :3, :] for f in opt.frame_ids[1:]], 0)
+        return ops.feature_warp_min_loss(tgt_f, src_f, outputs[("disp", 0, 0)].float(), P, inv_K,
+                                         opt.min_depth, opt.max_depth)
+
     def _masked_reconstruction(self, inputs, outputs, scale):
         """reference :80-91: photometric loss of the auto-encoder output against the resized target,
         averaged over erased pixels (mask == 0)."""
@@ -76,11 +94,16 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             for i in range(5):
                 loss_dict[("feature_regularization_loss", i)] = \
                     self.get_feature_regularization_loss(features[i], target) / (2 ** i) / 5
-            outputs = self.generate_features_pred(inputs, outputs)
-            tgt_f = features[0].float()
-            cands = [self.compute_perceptional_loss(tgt_f, outputs[("feature", f, 0)]) for f in opt.frame_ids[1:]]
-            vals, outputs["min_index"] = torch.min(torch.cat(cands, 1), dim=1)
-            loss_dict["min_perceptional_loss"] = opt.perception_weight * vals.mean()
+            fused = self._fused_feature_metric(inputs, outputs, features[0])
+            if fused is not None:
+                loss, outputs["min_index"] = fused
+                loss_dict["min_perceptional_loss"] = opt.perception_weight * loss
+            else:
+                outputs = self.generate_features_pred(inputs, outputs)
+                tgt_f = features[0].float()
+                cands = [self.compute_perceptional_loss(tgt_f, outputs[("feature", f, 0)]) for f in opt.frame_ids[1:]]
+                vals, outputs["min_index"] = torch.min(torch.cat(cands, 1), dim=1)
+                loss_dict["min_perceptional_loss"] = opt.perception_weight * vals.mean()
         ctx = self._begin_step(inputs)
         for scale in opt.scales:
             if features is not None and opt.get("img_reconstruct_weight", 1) != 0:

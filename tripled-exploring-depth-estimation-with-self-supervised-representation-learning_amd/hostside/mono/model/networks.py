@@ -14,7 +14,45 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-BatchNorm = nn.BatchNorm2d
+
+
+class BatchNorm(nn.BatchNorm2d):
+    """nn.BatchNorm2d with the per-layer ``num_batches_tracked += 1`` taken out of forward().  The
+    counter is not used by the computation when momentum is a number (0.1 here); bumping 252 of them
+    one tiny kernel at a time costs ~1 ms per step, so ``bump_batch_counters(model)`` advances all of
+    them with a single multi-tensor add once per training forward.  Same parameters/buffers/state_dict
+    keys and the same outputs as nn.BatchNorm2d."""
+
+    _pending = 0
+
+    def forward(self, x):
+        if self.training and self.track_running_stats and self.momentum is not None:
+            self._pending += 1
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
+                                self.momentum, self.eps)
+        return super().forward(x)
+
+
+def bump_batch_counters(model):
+    """num_batches_tracked += (forward calls since the last bump) for every BatchNorm of ``model``,
+    as one multi-tensor add."""
+    counters, amounts = [], []
+    for m in model.modules():
+        if isinstance(m, BatchNorm) and m._pending:
+            counters.append(m.num_batches_tracked)
+            amounts.append(m._pending)
+            m._pending = 0
+    if counters:
+        torch._foreach_add_(counters, amounts)
+
+
+def install_counter_hook(model):
+    """Advance the BatchNorm counters once per training forward of ``model``."""
+    def hook(module, args, output):
+        if module.training:
+            bump_batch_counters(module)
+    model.register_forward_hook(hook)
+
 
 # (block kind, blocks per stage)  -- reference: mono/model/mono_fm_joint/resnet.py:147-187
 RESNET_SPECS = {18: ("basic", (2, 2, 2, 2)), 34: ("basic", (3, 4, 6, 3)),

@@ -337,3 +337,75 @@ def reflpad1(x):
     if not reflpad1_supported(x):
         raise native.NativeLibraryError("reflpad1 needs a channels_last f32/bf16 HIP tensor with C % 8 == 0")
     return _ReflPad1.apply(x)
+
+
+class _FeatureWarpLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tgt_f, disp, P, invK, min_depth, max_depth, *src_f):
+        lib = native.load()
+        B, C, h, w = tgt_f.shape
+        hs, ws = disp.shape[2], disp.shape[3]
+        dev = tgt_f.device
+        n_src = len(src_f)
+        disp = _f32c(disp)
+        P = _f32c(P)
+        argmin = torch.empty(B, h, w, device=dev, dtype=torch.uint8)
+        nblk = lib.td_featwarp_num_blocks(B, h, w)
+        partial = torch.empty(nblk, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_featwarp_fwd(_raw(tgt_f), native.ptr_array(src_f), n_src, native.DTYPE_CODES[tgt_f.dtype],
+                                         native.ptr(disp), native.ptr(P), native.ptr(invK), B, h, w, C, hs, ws,
+                                         float(min_depth), float(max_depth), native.ptr(argmin), native.ptr(partial), st),
+                     "td_featwarp_fwd")
+        inv_count = 1.0 / float(B * h * w)
+        native.check(lib.td_sum_scaled(native.ptr(partial), nblk, inv_count, native.ptr(loss), st), "td_sum_scaled")
+        ctx.save_for_backward(tgt_f, disp, P, invK, argmin, *src_f)
+        ctx.meta = (min_depth, max_depth, inv_count, nblk)
+        ctx.mark_non_differentiable(argmin)
+        return loss.reshape(()), argmin
+
+    @staticmethod
+    def backward(ctx, g, _g_idx):
+        lib = native.load()
+        tgt_f, disp, P, invK, argmin, *src_f = ctx.saved_tensors
+        min_depth, max_depth, inv_count, nblk = ctx.meta
+        B, C, h, w = tgt_f.shape
+        hs, ws = disp.shape[2], disp.shape[3]
+        dev = tgt_f.device
+        n_src = len(src_f)
+        gs = _f32c(g.reshape(1))
+        d_tgt = torch.empty_like(tgt_f, memory_format=torch.channels_last)
+        d_src32 = [torch.zeros((B, h, w, C), device=dev, dtype=torch.float32) for _ in src_f]
+        d_up = torch.empty(B, h, w, device=dev, dtype=torch.float32)
+        dP_part = torch.empty(nblk, n_src * 12, device=dev, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_featwarp_bwd(_raw(tgt_f), native.ptr_array(src_f), n_src, native.DTYPE_CODES[tgt_f.dtype],
+                                         native.ptr(disp), native.ptr(P), native.ptr(invK), native.ptr(argmin),
+                                         native.ptr(gs), inv_count, B, h, w, C, hs, ws, float(min_depth),
+                                         float(max_depth), _raw(d_tgt), native.ptr_array(d_src32), native.ptr(d_up),
+                                         native.ptr(dP_part), st), "td_featwarp_bwd")
+        d_disp = torch.empty_like(disp)
+        native.check(lib.td_upsample_adjoint(native.ptr(d_up), B, h, w, hs, ws, native.ptr(d_disp), 0, st),
+                     "td_upsample_adjoint")
+        dP = torch.empty_like(P)
+        native.check(lib.td_reduce_partials(native.ptr(dP_part), n_src, B, nblk // B, native.ptr(dP), st),
+                     "td_reduce_partials")
+        # NHWC f32 accumulators -> logical NCHW view in the feature dtype (still channels-last memory)
+        d_src = tuple(d.permute(0, 3, 1, 2).to(tgt_f.dtype) for d in d_src32)
+        return (d_tgt, d_disp, dP, None, None, None) + d_src
+
+
+def featwarp_supported(tgt_f, src_f):
+    ok = lambda t: (t.is_cuda and t.dim() == 4 and t.dtype in native.DTYPE_CODES and t.shape[1] % 64 == 0
+                    and t.is_contiguous(memory_format=torch.channels_last))
+    return ok(tgt_f) and all(ok(s) and s.dtype == tgt_f.dtype and s.shape == tgt_f.shape for s in src_f) \
+        and 1 <= len(src_f) <= 2 and tgt_f.shape[2] >= 2 and tgt_f.shape[3] >= 2
+
+
+def feature_warp_min_loss(tgt_f, src_f, disp, P, invK, min_depth, max_depth):
+    """mean over pixels of min_f mean_c sqrt((tgt_f - warp_f(src_f))^2 + 1e-6): generate_features_pred +
+    compute_perceptional_loss + min over frames (reference: mono_fm_joint/net.py:196-223,63-65;
+    mono_fm_joint_inpaint/net.py:58-70).  P / invK are at the feature resolution.
+    Returns (loss, argmin uint8 [B,h,w])."""
+    return _FeatureWarpLoss.apply(tgt_f, disp, P, _f32c(invK), min_depth, max_depth, *src_f)
