@@ -173,6 +173,12 @@ def cpu_baseline(cfg_path, batch_size, steps):
     """The same training step on the host: fp32 networks + the CPU oracle loss path (a port of
     the reference's unfused PyTorch ops, pinned against the reference in tests/)."""
     from oracle.backend import OracleLossBackend
+    # the GPU box gives one-GPU jobs a 16-core share; more threads than that only oversubscribes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, int(os.environ.get("TD_CPU_THREADS", "16")))))
     cfg = Config.fromfile(cfg_path)
     cfg.model["imgs_per_gpu"] = batch_size
     torch.manual_seed(1024)

@@ -1,2 +1,3 @@
-timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "amdgpu.ids" | tail -3
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --miopen-find off 2>&1 | grep -v "amdgpu.ids\|Warning\|run_backward" | tail -1 | cut -c1-330
+mkdir -p gpurun_out
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_full.log 2>&1; echo rc=$?
+grep -v "amdgpu.ids\|Warning\|run_backward" gpurun_out/bench_full.log | tail -1

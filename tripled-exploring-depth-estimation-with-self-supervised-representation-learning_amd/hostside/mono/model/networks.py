@@ -499,7 +499,7 @@ class ColorDecoder(Decoder):
         def with_disp(x, scale):
             dsp = F.interpolate(outputs[("disp", frame_id, scale)], list(x.shape[2:]), mode="bilinear",
                                 align_corners=False)
-            return dsp * m
+            return (dsp * m).to(x.dtype)     # keep the decoder trunk in the activation dtype under autocast
 
         u5 = upsample(self.upconv5(e5))
         i5 = self.iconv5(u5) + with_disp(u5, 3)
