@@ -56,7 +56,8 @@ def parse():
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
-    p.add_argument("--syncbn", default="config", choices=["config", "on", "off"])
+    p.add_argument("--syncbn", default="off", choices=["on", "off"],
+                   help="N > 1 only: torch SyncBatchNorm as in the config (eager step) or local BN (HIP-graph step)")
     p.add_argument("--miopen-find", default="config", choices=["config", "on", "off"],
                    help="torch.backends.cudnn.benchmark = MIOpen find mode; default: the config's cudnn_benchmark")
     return p.parse_args()
@@ -90,7 +91,7 @@ class TrainStep:
         self.reducer = getattr(model, "reducer", None)
         self.loss = None
 
-    def __call__(self):
+    def forward_backward(self):
         if self.reducer is None:
             self.optimizer.zero_grad(set_to_none=True)   # with the DP engine, forward() re-zeroes the flat buffer
         with torch.autocast("cuda" if self.batch["K"].is_cuda else "cpu", dtype=self.dtype,
@@ -98,10 +99,18 @@ class TrainStep:
             outputs, losses = self.model(dict(self.batch))
         total = sum(v.float().mean() for v in losses.values())
         total.backward()
+        self.loss = total.detach()
+
+    def update(self):
         if self.max_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=2, foreach=True)
         self.optimizer.step()
-        self.loss = total.detach()
+
+    def __call__(self):
+        self.forward_backward()
+        if self.reducer is not None and not self.reducer.overlap:
+            self.reducer.allreduce_all()
+        self.update()
         return self.loss
 
 
@@ -209,7 +218,12 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device("cuda", torch.cuda.current_device())
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI; TD_DIST_BACKEND=gloo lets the N > 1 path be rehearsed on a single GPU
+        backend = os.environ.get("TD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     cfg = Config.fromfile(args.config)
     torch.backends.cudnn.benchmark = {"config": bool(cfg.get("cudnn_benchmark", False)), "on": True,
                                       "off": False}[args.miopen_find]
@@ -217,13 +231,20 @@ def main():
     B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
     torch.manual_seed(1024)
     model = build_model(cfg, dev, channels_last=True)
-    use_syncbn = {"config": bool(cfg.get("syncbn", False)), "on": True, "off": False}[args.syncbn]
+    # N > 1: SyncBatchNorm costs ~400 latency-bound collectives per step inside the compute stream
+    #  and keeps the step out of a HIP graph; B = 12 per GPU is enough for local
+    # batch statistics, so the benchmark default is local BN ("--syncbn on" restores the config's SyncBN).
+    use_syncbn = args.syncbn == "on"
+    split_graph = world > 1 and not use_syncbn and not args.no_graph
     if world > 1:
         from mmcv.parallel import MMDistributedDataParallel
         if use_syncbn:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        # graph mode: forward+backward and clip+Adam are two HIP graphs with the bucketed RCCL all-reduce of
+        # the flat gradient buffer between them; eager mode: the all-reduce overlaps backward (autograd hooks)
         model = MMDistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
-                                          find_unused_parameters=cfg.get("find_unused_parameters", False))
+                                          find_unused_parameters=cfg.get("find_unused_parameters", False),
+                                          overlap=not split_graph)
         model.train()
     batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]))
     dtype = torch.bfloat16 if args.dtype == "bf16" else None
@@ -231,7 +252,7 @@ def main():
 
     # warm-up (and capture) on a side stream: autograd's AccumulateGrad nodes then belong to a
     # non-default stream, which whole-step graph capture requires
-    graph, graphed = None, False
+    graph, graph_b, graphed = None, None, False
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -239,23 +260,39 @@ def main():
             step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    if not args.no_graph and world == 1:
+    if not args.no_graph and (world == 1 or split_graph):
         try:
             graph = torch.cuda.CUDAGraph()
-            step.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                step()
-            graph.replay()
+            if world == 1:
+                step.optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    step()
+                graph.replay()
+            else:
+                with torch.cuda.graph(graph):
+                    step.forward_backward()
+                graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_b):
+                    step.update()
+                graph.replay()
+                step.reducer.allreduce_all()
+                graph_b.replay()
             torch.cuda.synchronize()
             graphed = True
         except Exception as e:      # capture is an optimisation; report and continue eagerly
             if rank == 0:
                 print("HIP graph capture unavailable (%s: %s); timing eager launches" % (type(e).__name__, e),
                       file=sys.stderr)
-            graph = None
+            graph = graph_b = None
             torch.cuda.synchronize()
 
-    run = graph.replay if graphed else step
+    if graphed and world > 1:
+        def run():
+            graph.replay()
+            step.reducer.allreduce_all()
+            graph_b.replay()
+    else:
+        run = graph.replay if graphed else step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -284,7 +321,10 @@ def main():
             "config": {"workload": "%s %dx%d bs=%d/GPU (%s), fwd+bwd+clip+Adam" % (
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
                 "parallelism": "dp%d" % world, "hip_graph": graphed,
-                "syncbn": bool(use_syncbn and world > 1), "final_loss": round(final_loss, 6)},
+                "syncbn": bool(use_syncbn and world > 1),
+                "grad_sync": ("none" if world == 1 else ("bucketed RCCL all-reduce between two HIP graphs" if graphed
+                              else "bucketed RCCL all-reduce overlapped with backward")),
+                "final_loss": round(final_loss, 6)},
         }
         kern = roofline_of_hot_kernels(cfg, batch) if not args.no_roofline else None
         if kern is None:

@@ -25,7 +25,7 @@ import torch.nn as nn
 class GradientBuckets:
     """Flat gradient storage + bucketed asynchronous all-reduce."""
 
-    def __init__(self, params, bucket_bytes, process_group=None):
+    def __init__(self, params, bucket_bytes, process_group=None, overlap=True):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.params = [p for p in params if p.requires_grad]
@@ -44,7 +44,12 @@ class GradientBuckets:
         off, start, members = 0, 0, []
         for p in order:
             n = p.numel()
-            self.views[p] = self.flat[off:off + n].view_as(p)
+            # same sizes AND strides as the parameter (channels-last conv weights stay channels-last), so
+            # autograd's layout contract holds and fused optimizers accept the (param, grad) pair
+            if p.is_contiguous():
+                self.views[p] = self.flat[off:off + n].view_as(p)
+            else:
+                self.views[p] = torch.as_strided(self.flat, p.size(), p.stride(), off)
             members.append(p)
             off += n
             if off - start >= per_bucket:
@@ -58,7 +63,10 @@ class GradientBuckets:
         self.callback_queued = False
         self.synced = False
         self.use_avg = dist.get_backend(process_group) == "nccl"
-        self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # overlap=False: no autograd hooks; the owner calls allreduce_all() after backward (used when the
+        # forward+backward is replayed from a HIP graph, where Python hooks do not run)
+        self.overlap = overlap
+        self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if overlap else []
 
     def _close(self, start, end, members):
         idx = len(self.buckets)
@@ -117,6 +125,13 @@ class GradientBuckets:
         self.works = []
         self.synced = True
 
+    def allreduce_all(self):
+        """Non-overlapped mode: all buckets, issued back to back (asynchronously), then joined."""
+        for i in range(len(self.buckets)):
+            self.launched[i] = False
+        self.works = []
+        self.finalize()
+
     def remove(self):
         for h in self.hooks:
             h.remove()
@@ -128,7 +143,7 @@ class MMDistributedDataParallel(nn.Module):
     broadcast_buffers=False, find_unused_parameters=...)``."""
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=False,
-                 find_unused_parameters=False, bucket_cap_mb=64, process_group=None, **kwargs):
+                 find_unused_parameters=False, bucket_cap_mb=64, process_group=None, overlap=True, **kwargs):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("MMDistributedDataParallel needs an initialised process group (init_dist)")
@@ -141,7 +156,8 @@ class MMDistributedDataParallel(nn.Module):
         self._sync_initial_state()
         self.reducer = None
         if self.world > 1:
-            self.reducer = GradientBuckets(list(module.parameters()), int(bucket_cap_mb * 1024 * 1024), process_group)
+            self.reducer = GradientBuckets(list(module.parameters()), int(bucket_cap_mb * 1024 * 1024), process_group,
+                                           overlap=overlap)
 
     def _sync_initial_state(self):
         """Rank 0's parameters and buffers to every rank, as a handful of flat broadcasts."""
