@@ -94,7 +94,16 @@ def build_optimizer(model, optimizer_cfg):
     return getattr(torch.optim, optimizer_cfg.pop("type"))(groups, **optimizer_cfg)
 
 
+def _maybe_prefetch(loaders, cfg):
+    """Overlap the host->device copy of batch t+1 with step t (cfg.device_prefetch, default on with a GPU)."""
+    if torch.cuda.is_available() and cfg.get("device_prefetch", True):
+        from mono.datasets import DevicePrefetcher
+        return [DevicePrefetcher(dl) for dl in loaders]
+    return loaders
+
+
 def _finish_runner(runner, cfg, data_loaders):
+    data_loaders = _maybe_prefetch(data_loaders, cfg)
     if cfg.resume_from:
         runner.resume(cfg.resume_from)
     elif cfg.load_from:

@@ -1,3 +1,4 @@
 from .loader import DistributedGroupSampler, DistributedSampler, GroupSampler, build_dataloader  # noqa: F401
 from .get_dataset import get_dataset  # noqa: F401
 from .synthetic import SyntheticTripletDataset, synthetic_batch  # noqa: F401
+from .prefetch import DevicePrefetcher  # noqa: F401

@@ -51,8 +51,9 @@ class Project(nn.Module):
         cam = torch.matmul(torch.matmul(K, T)[:, :3, :], points)
         uv = cam[:, :2, :] / (cam[:, 2:3, :] + self.eps)
         uv = uv.view(self.batch_size, 2, self.height, self.width).permute(0, 2, 3, 1)
-        scale = torch.tensor([self.width - 1, self.height - 1], device=uv.device, dtype=uv.dtype)
-        return (uv / scale - 0.5) * 2
+        u = uv[..., 0] / (self.width - 1)
+        v = uv[..., 1] / (self.height - 1)
+        return (torch.stack([u, v], dim=-1) - 0.5) * 2
 
 
 class SSIM(nn.Module):

@@ -18,8 +18,8 @@ def rgb2xyz(rgb):
 
 
 def xyz2lab(xyz):
-    white = torch.tensor(_WHITE, device=xyz.device, dtype=xyz.dtype).view(1, 3, 1, 1)
-    s = xyz / white
+    # per-channel scalar division: no host->device constant upload (legal inside HIP graph capture)
+    s = torch.stack([xyz[:, 0] / _WHITE[0], xyz[:, 1] / _WHITE[1], xyz[:, 2] / _WHITE[2]], dim=1)
     f = torch.where(s > 0.008856, s ** (1 / 3.0), 7.787 * s + 16.0 / 116.0)
     L = 116.0 * f[:, 1] - 16.0
     a = 500.0 * (f[:, 0] - f[:, 1])
