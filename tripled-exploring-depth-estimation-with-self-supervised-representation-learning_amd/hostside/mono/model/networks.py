@@ -9,6 +9,8 @@ section 5): e.g. ``DepthEncoder.encoder.layer1.0.conv1.weight``, ``DepthDecoder.
 The convolutions are the one dense contraction of the step; they run on MFMA through
 PyTorch-ROCm (MIOpen / hipBLASLt) under bf16 autocast with channels_last activations.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -304,8 +306,18 @@ class Conv1x1(nn.Module):
         return self.conv(x)
 
 
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
 class Conv3x3(nn.Module):
-    """3x3 conv after a 1-pixel reflection (or zero) pad."""
+    """3x3 conv after a 1-pixel reflection (or zero) pad.
+
+    On HIP devices channel counts that are not multiples of 8 are zero-padded on the fly (input channels:
+    513 -> 520 for the CRP decoder's concat convs; output channels: 1 / 2 / 3 -> 8 for the disparity and
+    image heads).  The parameters keep the reference's shapes (checkpoint keys); zero channels contribute
+    nothing and the extra outputs are sliced away, but MIOpen's vectorised implicit-GEMM kernels then apply
+    (513->256 @48x160: 976 us -> ~420 us forward, 2.2 ms -> ~0.9 ms backward on MI355X)."""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
@@ -313,12 +325,35 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
-    def forward(self, x):
-        if self.use_refl and x.is_cuda and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
+    def _pad_input(self, x):
+        if self.use_refl and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] >= 2 and x.shape[3] >= 2:
             from tripled_amd import ops          # gather-form pad / adjoint (ATen's backward uses atomics)
-            return self.conv(ops.reflpad1(x))
-        return self.conv(self.pad(x))
+            return ops.reflpad1(x)
+        return self.pad(x)
+
+    def forward(self, x):
+        # bf16 (autocast) only: MIOpen's f32 NHWC backward-data path crashes for 8-channel outputs
+        # (conv -n 2 -c 16 -H 98 -W 162 -k 8 -y 3 -x 3, ROCm 7.2), so f32 models keep the plain convolution
+        low_precision = x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())
+        if not low_precision or os.environ.get("TD_NO_CHANNEL_PAD"):
+            return self.conv(self._pad_input(x) if x.is_cuda else self.pad(x))
+        w, b = self.conv.weight, self.conv.bias
+        cout, cin = w.shape[0], w.shape[1]
+        cin_p, cout_p = _round8(cin), _round8(cout)
+        if cin_p == cin and cout_p == cout and x.shape[1] == cin:
+            return self.conv(self._pad_input(x))
+        if x.shape[1] == cin and cin_p != cin:               # caller did not pre-pad the channels
+            x = torch.cat((x, x.new_zeros(x.shape[0], cin_p - cin, x.shape[2], x.shape[3])), 1)
+        if x.shape[1] != cin_p:
+            raise ValueError("Conv3x3 expects %d (or pre-padded %d) input channels, got %d" % (cin, cin_p, x.shape[1]))
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
+        if b is not None and cout_p != cout:
+            b = F.pad(b, (0, cout_p - cout))
+        y = F.conv2d(self._pad_input(x), w, b)
+        return y[:, :cout] if cout_p != cout else y
 
 
 class Conv5x5(nn.Module):
@@ -428,10 +463,18 @@ class DepthDecoder(nn.Module):
         _, l1, l2, l3, l4 = input_features
         l4 = self.do(l4)
         l3 = self.do(l3)
+        def joined(r, x, d):
+            parts = [r, x, d.to(x.dtype)]
+            c = sum(p.shape[1] for p in parts)
+            if x.is_cuda and c % 8 and x.dtype == torch.bfloat16 and not os.environ.get("TD_NO_CHANNEL_PAD"):
+                # 513 -> 520 zero channels: see Conv3x3
+                parts.append(x.new_zeros(x.shape[0], _round8(c) - c, x.shape[2], x.shape[3]))
+            return torch.cat(parts, 1)
+
         x, d4 = self._stage(4, self.reduce4(l4))
-        x, d3 = self._stage(3, torch.cat((self.reduce3(l3), x, d4), 1))
-        x, d2 = self._stage(2, torch.cat((self.reduce2(l2), x, d3), 1))
-        x, d1 = self._stage(1, torch.cat((self.reduce1(l1), x, d2), 1))
+        x, d3 = self._stage(3, joined(self.reduce3(l3), x, d4))
+        x, d2 = self._stage(2, joined(self.reduce2(l2), x, d3))
+        x, d1 = self._stage(1, joined(self.reduce1(l1), x, d2))
         self.outputs = {("disp", frame_id, 3): d4, ("disp", frame_id, 2): d3,
                         ("disp", frame_id, 1): d2, ("disp", frame_id, 0): d1}
         return self.outputs
