@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-graph", action="store_true", help="do not capture the step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--split-timing", action="store_true", help="two graphs (fwd+bwd | clip+Adam) and report each")
+    p.add_argument("--flat", action="store_true", help="flat bf16/fp32 parameter store (tripled_amd/flat_amp.py) instead of autocast + per-parameter Adam")
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
@@ -77,39 +79,57 @@ class TrainStep:
     batch_processor + DistOptimizerHook do per iteration, mono/apis/trainer.py:32-60,
     mono/core/utils/dist_utils.py:54-60)."""
 
-    def __init__(self, model, cfg, batch, autocast_dtype):
+    def __init__(self, model, cfg, batch, autocast_dtype, flat=False):
         self.model, self.batch, self.dtype = model, batch, autocast_dtype
         inner = model.module if hasattr(model, "module") else model
         self.params = [p for p in inner.parameters() if p.requires_grad]
         ocfg = dict(cfg.optimizer)
         assert ocfg.pop("type") == "Adam"
-        on_gpu = batch["K"].is_cuda
-        # fused multi-tensor Adam on the GPU (same update rule as torch.optim.Adam(lr, weight_decay=0))
-        self.optimizer = torch.optim.Adam(self.params, capturable=on_gpu, fused=on_gpu, **ocfg)
         clip = cfg.optimizer_config.get("grad_clip", None)
         self.max_norm = clip["max_norm"] if clip else None
         self.reducer = getattr(model, "reducer", None)
+        self.flat = None
+        on_gpu = batch["K"].is_cuda
+        if flat:
+            from tripled_amd.flat_amp import FlatMixedPrecision
+            self.flat = FlatMixedPrecision(inner, max_norm=self.max_norm, **ocfg)
+            self.optimizer = self.flat.optimizer
+        else:
+            # fused multi-tensor Adam on the GPU (same update rule as torch.optim.Adam(lr, weight_decay=0))
+            self.optimizer = torch.optim.Adam(self.params, capturable=on_gpu, fused=on_gpu, **ocfg)
         self.loss = None
 
     def forward_backward(self):
-        if self.reducer is None:
+        if self.flat is not None:
+            self.flat.zero_grad()
+        elif self.reducer is None:
             self.optimizer.zero_grad(set_to_none=True)   # with the DP engine, forward() re-zeroes the flat buffer
         with torch.autocast("cuda" if self.batch["K"].is_cuda else "cpu", dtype=self.dtype,
                             enabled=self.dtype is not None):
             outputs, losses = self.model(dict(self.batch))
         total = sum(v.float().mean() for v in losses.values())
         total.backward()
+        if self.flat is not None:
+            self.flat.collect()
         self.loss = total.detach()
 
+    def sync(self):
+        if self.flat is not None:
+            self.flat.allreduce()
+        elif self.reducer is not None and not self.reducer.overlap:
+            self.reducer.allreduce_all()
+
     def update(self):
+        if self.flat is not None:
+            self.flat.step()
+            return
         if self.max_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=2, foreach=True)
         self.optimizer.step()
 
     def __call__(self):
         self.forward_backward()
-        if self.reducer is not None and not self.reducer.overlap:
-            self.reducer.allreduce_all()
+        self.sync()
         self.update()
         return self.loss
 
@@ -235,20 +255,27 @@ def main():
     #  and keeps the step out of a HIP graph; B = 12 per GPU is enough for local
     # batch statistics, so the benchmark default is local BN ("--syncbn on" restores the config's SyncBN).
     use_syncbn = args.syncbn == "on"
-    split_graph = world > 1 and not use_syncbn and not args.no_graph
-    if world > 1:
+    dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    split_graph = (world > 1 or args.split_timing) and not use_syncbn and not args.no_graph
+    # flat bf16/fp32 parameter store: opt-in -- measured 2.1 ms/step SLOWER than plain autocast at C2
+    use_flat = dtype is not None and not use_syncbn and args.flat
+    if world > 1 and not use_flat:
         from mmcv.parallel import MMDistributedDataParallel
         if use_syncbn:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        # graph mode: forward+backward and clip+Adam are two HIP graphs with the bucketed RCCL all-reduce of
-        # the flat gradient buffer between them; eager mode: the all-reduce overlaps backward (autograd hooks)
+        # eager: the bucketed all-reduce overlaps backward (autograd hooks); split-graph: it runs between
+        # the forward+backward graph and the clip+Adam graph
         model = MMDistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
                                           find_unused_parameters=cfg.get("find_unused_parameters", False),
                                           overlap=not split_graph)
         model.train()
+    elif world > 1:
+        # flat path: rank 0's initial weights to everyone, then no wrapper at all -- the gradient exchange is
+        # FlatMixedPrecision.allreduce() on one contiguous fp32 buffer
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
     batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]))
-    dtype = torch.bfloat16 if args.dtype == "bf16" else None
-    step = TrainStep(model, cfg, batch, dtype)
+    step = TrainStep(model, cfg, batch, dtype, flat=use_flat)
 
     # warm-up (and capture) on a side stream: autograd's AccumulateGrad nodes then belong to a
     # non-default stream, which whole-step graph capture requires
@@ -263,8 +290,7 @@ def main():
     if not args.no_graph and (world == 1 or split_graph):
         try:
             graph = torch.cuda.CUDAGraph()
-            if world == 1:
-                step.optimizer.zero_grad(set_to_none=True)
+            if not split_graph:
                 with torch.cuda.graph(graph):
                     step()
                 graph.replay()
@@ -275,7 +301,7 @@ def main():
                 with torch.cuda.graph(graph_b):
                     step.update()
                 graph.replay()
-                step.reducer.allreduce_all()
+                step.sync()
                 graph_b.replay()
             torch.cuda.synchronize()
             graphed = True
@@ -286,10 +312,20 @@ def main():
             graph = graph_b = None
             torch.cuda.synchronize()
 
-    if graphed and world > 1:
+    if graphed and args.split_timing and rank == 0:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ta = tb = 0.0
+        for _ in range(10):
+            ev[0].record(); graph.replay(); ev[1].record(); step.sync(); graph_b.replay(); ev[2].record()
+            torch.cuda.synchronize()
+            ta += ev[0].elapsed_time(ev[1]) / 10
+            tb += ev[1].elapsed_time(ev[2]) / 10
+        print("split timing: forward+backward(+gather) graph %.3f ms, sync+clip+Adam graph %.3f ms" % (ta, tb),
+              file=sys.stderr)
+    if graphed and split_graph:
         def run():
             graph.replay()
-            step.reducer.allreduce_all()
+            step.sync()
             graph_b.replay()
     else:
         run = graph.replay if graphed else step

@@ -1,0 +1,146 @@
+"""Flat mixed-precision parameter store for the data-parallel training step.
+
+Under plain autocast every convolution weight is cast fp32 -> bf16 once per forward and every weight
+gradient bf16 -> fp32 once per backward: ~650 tiny kernels per step for the tripleD model, plus ~320
+per-parameter optimiser/clip launches.  Here all of that is a handful of large launches over
+contiguous HBM buffers (sized for a 288 GB device, where duplicating the weights costs nothing):
+
+  flat_w   fp32 master copy of EVERY parameter (module fp32 parameters are views into it)
+  flat_lp  bf16 working copy of the convolution weights/biases (module parameters are views into it);
+           refreshed from flat_w by ONE cast kernel after each optimiser step
+  flat_g   fp32 gradients of every parameter, filled by ONE multi-tensor copy after backward;
+           it is what the RCCL all-reduce runs on (few, large buckets) and what clip + Adam consume
+
+Numerically this is the autocast path: convolutions see bf16(weight) and produce bf16 weight gradients
+in both cases; the master update is the same fp32 Adam.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+import os
+ALIGN = int(os.environ.get('TD_FLAT_ALIGN', '8'))      # elements: 16 B in bf16, 32 B in fp32
+
+
+class FlatMixedPrecision:
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None,
+                 lowp_dtype=torch.bfloat16, process_group=None, bucket_bytes=64 << 20):
+        params = [p for p in model.parameters() if p.requires_grad]
+        dev = params[0].device
+        lowp_ids = set()
+        for m in model.modules():
+            if isinstance(m, nn.Conv2d) and os.environ.get('TD_FLAT_LOWP', '1') == '1':
+                for p in m.parameters(recurse=False):
+                    if p.requires_grad:
+                        lowp_ids.add(id(p))
+        self.lowp = [p for p in params if id(p) in lowp_ids]
+        self.full = [p for p in params if id(p) not in lowp_ids]
+        self.params = self.lowp + self.full
+        # every parameter starts on an 8-element boundary: the convolution kernels use 16-byte vector loads
+        # on their (bf16) weight pointer
+        offsets, off, n_lp = [], 0, 0
+        for p in self.params:
+            offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if self.lowp and p is self.lowp[-1]:
+                n_lp = off
+        n_all = off
+        self.flat_w = torch.zeros(n_all, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(n_all, device=dev, dtype=torch.float32)
+        self.flat_lp = torch.zeros(n_lp, device=dev, dtype=lowp_dtype)
+        self.flat_glp = torch.zeros(n_lp, device=dev, dtype=lowp_dtype)
+        self._pads = {}
+        self.n_lp = n_lp
+        self.offsets = offsets
+
+        def view(buf, p, off):
+            return torch.as_strided(buf, p.size(), p.stride(), off)    # keeps channels_last strides
+
+        with torch.no_grad():
+            for p, off in zip(self.params, offsets):
+                w_view = view(self.flat_w, p, off)
+                w_view.copy_(p)
+                if id(p) in lowp_ids:
+                    p.data = view(self.flat_lp, p, off)    # the module now computes with the bf16 working copy
+                else:
+                    p.data = w_view                        # fp32 parameters (BatchNorm, Linear) live in the master buffer
+            self.flat_lp.copy_(self.flat_w[:n_lp])
+        self.master = nn.Parameter(self.flat_w, requires_grad=True)
+        self.master.grad = self.flat_g
+        on_gpu = dev.type == "cuda"
+        self.optimizer = torch.optim.Adam([self.master], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                          capturable=on_gpu, fused=on_gpu)
+        self.max_norm = max_norm
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.use_avg = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        per = max(1, bucket_bytes // 4)
+        self.buckets = [(s, min(s + per, n_all)) for s in range(0, n_all, per)]
+
+    def zero_grad(self):
+        """Gradients are produced fresh by autograd each step (set_to_none) and gathered by collect()."""
+        for p in self.params:
+            p.grad = None
+
+    def _flat_sources(self, params, offsets, end, dtype):
+        """Per-parameter gradients as 1-D memory-order views, interleaved with the zero pads of the flat layout."""
+        out = []
+        for i, (p, off) in enumerate(zip(params, offsets)):
+            n = p.numel()
+            g = p.grad
+            if g is None:
+                g = self._zeros(n, dtype)                      # unused parameter: its slot stays zero
+            elif g.stride() != p.stride() or g.dtype != dtype:
+                g = self._relayout(g, p, dtype)                # rare: autograd normally follows the layout contract
+            out.append(torch.as_strided(g, (n,), (1,), g.storage_offset()))
+            nxt = offsets[i + 1] if i + 1 < len(offsets) else end
+            if nxt - off - n:
+                out.append(self._zeros(nxt - off - n, dtype))
+        return out
+
+    def _zeros(self, n, dtype):
+        key = (n, dtype)
+        if key not in self._pads:
+            self._pads[key] = torch.zeros(n, device=self.flat_g.device, dtype=dtype)
+        return self._pads[key]
+
+    @staticmethod
+    def _relayout(g, p, dtype):
+        out = torch.empty_strided(p.size(), p.stride(), device=g.device, dtype=dtype)
+        out.copy_(g)
+        return out
+
+    def collect(self):
+        """Per-parameter gradients (fresh autograd allocations, bf16 for convolutions / fp32 otherwise) -> the
+        flat fp32 gradient buffer: batched concatenations (128 tensors per launch) plus ONE bf16->fp32 cast."""
+        k = len(self.lowp)
+        if k:
+            torch.cat(self._flat_sources(self.lowp, self.offsets[:k], self.n_lp, self.flat_lp.dtype), out=self.flat_glp)
+            self.flat_g[:self.n_lp].copy_(self.flat_glp)
+        if self.full:
+            torch.cat(self._flat_sources(self.full, self.offsets[k:], self.flat_g.numel(), torch.float32),
+                      out=self.flat_g[self.n_lp:])
+
+    def allreduce(self):
+        """Average flat_g over the ranks: a few large RCCL all-reduces, issued back to back."""
+        if self.world == 1:
+            return
+        works = []
+        for s, e in self.buckets:
+            chunk = self.flat_g[s:e]
+            op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+            works.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk))
+        for w, chunk in works:
+            w.wait()
+            if not self.use_avg:
+                chunk.div_(self.world)
+
+    def step(self):
+        """clip_grad_norm_(max_norm, 2) + Adam on the flat buffers, then refresh the bf16 working copy."""
+        if self.max_norm is not None:
+            total = torch.linalg.vector_norm(self.flat_g)
+            self.flat_g.mul_(torch.clamp(self.max_norm / (total + 1e-6), max=1.0))
+        self.optimizer.step()
+        if self.n_lp:
+            self.flat_lp.copy_(self.flat_w[:self.n_lp])
