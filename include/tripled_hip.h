@@ -187,6 +187,28 @@ int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, 
                     void* grad_in, td_stream_t stream);
 
 /*
+ * Training-mode BatchNorm2d on channels-last activations with the residual add and ReLU of the ResNet
+ * blocks fused in (mono/model/mono_fm_joint/resnet.py:30-49 BasicBlock.forward, :66-86
+ * Bottleneck.forward; F.batch_norm(training=True) semantics: biased batch variance for the output,
+ * unbiased for running_var, running = (1 - momentum) * running + momentum * batch).
+ *
+ *   x, residual, y, dy, dx, dresidual : [M, C] row-major (= NHWC with M = N*H*W), dtype f32 or bf16, C % 64 == 0
+ *   gamma, beta, running_*, save_*, dgamma, dbeta : [C] f32 ; residual / running_* / dresidual may be NULL
+ *   y = relu?( (x - mean) * invstd * gamma + beta [+ residual] )
+ *   backward: g = dy * [y > 0] (relu; with y == NULL and no residual the mask is recomputed from x, gamma, beta,
+ *             save_mean, save_invstd exactly as the forward formed it) ; dbeta = sum g ; dgamma = sum g * xhat ;
+ *             dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M) ; dresidual = g
+ *   workspace: td_bn_workspace_floats(M, C) floats (partial sums + coefficients; contents undefined on return).
+ */
+long long td_bn_workspace_floats(long long M, int C);
+int td_bn_fwd(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
+              float* running_mean, float* running_var, float momentum, float eps, int relu, long long M, int C,
+              void* y, float* save_mean, float* save_invstd, float* workspace, td_stream_t stream);
+int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta, const float* save_mean,
+              const float* save_invstd, int relu, long long M, int C, void* dx, void* dresidual, float* dgamma,
+              float* dbeta, float* workspace, td_stream_t stream);
+
+/*
  * Edge-aware regulariser on C-channel feature maps: get_feature_regularization_loss,
  * mono/model/mono_fm_joint/net.py:309-330 (six stencil terms |d_k F| * exp(-a * mean_c |d_k I|)).
  *

@@ -1,0 +1,76 @@
+"""HIP BatchNorm(+residual)(+ReLU) vs ATen's F.batch_norm -> add -> relu in fp32 (reference blocks:
+mono/model/mono_fm_joint/resnet.py:30-49, 66-86)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import tripled_amd  # noqa: F401
+from tripled_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x, w, b, rm, rv, res, relu, dy):
+    x = x.detach().float().requires_grad_(True)
+    w = w.detach().clone().requires_grad_(True)
+    b = b.detach().clone().requires_grad_(True)
+    res = res.detach().float().requires_grad_(True) if res is not None else None
+    y = F.batch_norm(x, rm, rv, w, b, True, 0.1, 1e-5)
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.float())
+    return y.detach(), x.grad, w.grad, b.grad, (res.grad if res is not None else None)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 5, 7), (3, 128, 17, 33), (12, 64, 48, 160), (4, 2048, 6, 20), (1, 64, 1, 3)])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_act_matches_aten(shape, relu, with_res, dtype):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(hash((shape, relu, with_res)) % 1000)
+    N, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.3).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(shape, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last) if with_res else None
+    dy = torch.randn(shape, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.rand(C, generator=g) + 0.5).to(dev)
+    b = (torch.randn(C, generator=g) * 0.2).to(dev)
+    rm0, rv0 = torch.randn(C, generator=g).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+
+    rm_ref, rv_ref = rm0.clone(), rv0.clone()
+    y_ref, dx_ref, dw_ref, db_ref, dres_ref = _reference(x, w, b, rm_ref, rv_ref, res, relu, dy)
+
+    xh = x.clone().requires_grad_(True)
+    wh, bh = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    resh = res.clone().requires_grad_(True) if with_res else None
+    rm, rv = rm0.clone(), rv0.clone()
+    y = ops.batchnorm_act(xh, wh, bh, rm, rv, 0.1, 1e-5, residual=resh, relu=relu)
+    assert y.dtype == dtype and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    # fp32: summation order only; bf16: one output rounding (2^-8 relative) on O(1..5) values
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)
+    assert torch.allclose(y.float(), y_ref, **tol)
+    assert torch.allclose(rm, rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv_ref, rtol=1e-5, atol=1e-6)
+    M = N * H * W
+    gtol = dict(rtol=1e-4, atol=1e-4 * M ** 0.5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2 * M ** 0.5)
+    assert torch.allclose(wh.grad, dw_ref, **gtol) and torch.allclose(bh.grad, db_ref, **gtol)
+    dtol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(xh.grad.float(), dx_ref, **dtol)
+    if with_res:
+        assert torch.allclose(resh.grad.float(), dres_ref, **dtol)
+
+
+def test_resnet_block_uses_fused_bn():
+    """The encoders' blocks give the same result through the fused path and through ATen (TD_NO_FUSED_BN)."""
+    from mono.model import networks
+    torch.manual_seed(0)
+    blk = networks.Bottleneck(256, 64).cuda().to(memory_format=torch.channels_last).train()
+    x = torch.randn(2, 256, 12, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    ya = blk(x)
+    networks.FUSED_BN_OFF = True
+    try:
+        yb = blk(x)
+    finally:
+        networks.FUSED_BN_OFF = False
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)

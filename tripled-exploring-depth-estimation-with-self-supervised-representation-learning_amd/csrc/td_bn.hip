@@ -1,0 +1,354 @@
+// Training-mode batch normalisation of channels-last activations with the residual add and ReLU that
+// follow it in every ResNet block of the encoders fused in (reference: mono/model/mono_fm_joint/resnet.py:
+// 30-49 BasicBlock.forward, 66-86 Bottleneck.forward: conv -> bn -> [+ identity] -> relu).
+//
+// The activation tensor is a row-major [M, C] matrix (M = N*H*W pixels, C channels, C % 64 == 0).  A
+// block is 8 x 32 threads: 8 threads x 8 channels cover one 64-channel group of a row with 16-byte
+// loads, 32 rows per iteration, four iterations in flight.  Per-channel sums are two-stage and
+// deterministic: per-block partials -> one finalize block per channel group (kernel boundaries are the
+// only inter-block synchronisation; no atomics, no fences).
+//
+//   forward : stats (sum x, sum x^2 partials) -> finalize (mean, 1/std, running stats)
+//             -> apply   y = relu?( (x - mean) * invstd * gamma + beta [+ residual] )
+//   backward: reduce (sum g, sum g*(x-mean) partials; g = dy * [y > 0])  -> finalize (dgamma, dbeta, dx coefficients)
+//             -> dx = gamma*invstd * (g - dbeta/M - xhat * dgamma/M),  dresidual = g
+#include <hip/hip_bf16.h>
+
+#include "td_common.h"
+#include "td_vec8.h"
+
+namespace td {
+
+constexpr int BN_RY = 32;        // rows per block iteration
+constexpr int BN_UNROLL = 4;     // row iterations in flight
+constexpr int BN_THREADS = 256;  // 8 channel-vector lanes x 32 rows
+
+// ---------------------------------------------------------------------------------------------
+// per-channel partial sums of a [rows, 64-channel] slab: MODE 0: (x, x^2)   MODE 1: (g, g * (x - mean))
+// ---------------------------------------------------------------------------------------------
+// relu: 0 none, 1 mask = [y > 0] read from y, 2 mask recomputed from x as [fma(x, gamma*invstd, beta - mean*gamma*invstd) > 0]
+// (exactly the forward's pre-activation value; only valid without a residual)
+template <typename T, int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 const T* __restrict__ y, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 long long M, int C, int rows_per_split, int relu,
+                                                                 float* __restrict__ ws) {
+  __shared__ float lds[2][BN_RY][64 + 1];
+  const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
+  const int cg = blockIdx.x, s = blockIdx.y;
+  const long long r0 = (long long)s * rows_per_split;
+  const long long r1 = (r0 + rows_per_split < M) ? r0 + rows_per_split : M;
+  const size_t col = (size_t)cg * 64 + (size_t)cx * 8;
+  float a[8], b[8], mu[8], sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; sc[i] = 0.f; sh[i] = 0.f; }
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mu[i] = mean[col + i];
+    if (relu == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sc[i] = gamma[col + i] * invstd[col + i];
+        sh[i] = beta[col + i] - mu[i] * sc[i];
+      }
+    }
+  }
+  for (long long r = r0 + ry; r < r1; r += BN_UNROLL * BN_RY) {
+    float vx[BN_UNROLL][8], vg[BN_UNROLL][8], vy[BN_UNROLL][8];
+    bool ok[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {       // unconditional loads from clamped (valid) rows
+      const long long rr = r + (long long)u * BN_RY;
+      ok[u] = rr < r1;
+      const size_t off = (size_t)(ok[u] ? rr : r) * C + col;
+      load8(x + off, vx[u]);
+      if (MODE == 1) {
+        load8(dy + off, vg[u]);
+        if (relu == 1) load8(y + off, vy[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (MODE == 0) {
+          const float t = ok[u] ? vx[u][i] : 0.f;
+          a[i] += t;
+          b[i] = fmaf(t, t, b[i]);
+        } else {
+          float g = vg[u][i];
+          if (relu == 1) g = vy[u][i] <= 0.f ? 0.f : g;   // threshold_backward
+          if (relu == 2) g = fmaf(vx[u][i], sc[i], sh[i]) <= 0.f ? 0.f : g;
+          g = ok[u] ? g : 0.f;
+          a[i] += g;
+          b[i] = fmaf(g, vx[u][i] - mu[i], b[i]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { lds[0][ry][cx * 8 + i] = a[i]; lds[1][ry][cx * 8 + i] = b[i]; }
+  __syncthreads();
+  if (tid < 128) {
+    const int which = tid >> 6, c = tid & 63;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < BN_RY; ++j) acc += lds[which][j][c];
+    ws[((size_t)s * C + (size_t)cg * 64 + c) * 2 + which] = acc;
+  }
+}
+
+// sums the S partials of one 64-channel group; result (sumA, sumB) valid in threads 0..63
+constexpr int BN_FIN_PARTS = 16;                      // finalize block: 64 channels x 16 slices of the S partials
+constexpr int BN_FIN_THREADS = 64 * BN_FIN_PARTS;
+__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, int S, int C, int cg, float& A, float& B) {
+  __shared__ float red[2][BN_FIN_PARTS][64];
+  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  float a = 0.f, b = 0.f;
+#pragma unroll 4
+  for (int s = part; s < S; s += BN_FIN_PARTS) {
+    const float2 p = *reinterpret_cast<const float2*>(ws + ((size_t)s * C + (size_t)cg * 64 + c) * 2);
+    a += p.x;
+    b += p.y;
+  }
+  red[0][part][c] = a;
+  red[1][part][c] = b;
+  __syncthreads();
+  A = 0.f;
+  B = 0.f;
+  if (tid < 64) {
+#pragma unroll
+    for (int j = 0; j < BN_FIN_PARTS; ++j) { A += red[0][j][c]; B += red[1][j][c]; }
+  }
+}
+
+__global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_fwd_kernel(const float* __restrict__ ws, int S, int C, long long M,
+                                                                    float eps, float momentum,
+                                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  float A, B;
+  bn_sum_partials(ws, S, C, blockIdx.x, A, B);
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const double m = (double)A / (double)M;
+    double var = (double)B / (double)M - m * m;      // biased variance, formed in double
+    var = var > 0.0 ? var : 0.0;
+    save_mean[c] = (float)m;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              long long M, int C, int rows_per_split, int relu, T* __restrict__ y) {
+  const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
+  const long long r0 = (long long)blockIdx.y * rows_per_split;
+  const long long r1 = (r0 + rows_per_split < M) ? r0 + rows_per_split : M;
+  const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = gamma[col + i] * invstd[col + i];
+    sh[i] = beta[col + i] - mean[col + i] * sc[i];
+  }
+  for (long long r = r0 + ry; r < r1; r += BN_UNROLL * BN_RY) {
+    float vx[BN_UNROLL][8], vr[BN_UNROLL][8];
+    bool ok[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      const long long rr = r + (long long)u * BN_RY;
+      ok[u] = rr < r1;
+      const size_t off = (size_t)(ok[u] ? rr : r) * C + col;
+      load8(x + off, vx[u]);
+      if (res) load8(res + off, vr[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v = fmaf(vx[u][i], sc[i], sh[i]);
+        if (res) v += vr[u][i];
+        if (relu) v = v < 0.f ? 0.f : v;       // NaN propagates, like ATen's relu
+        o[i] = v;
+      }
+      if (ok[u]) store8(y + (size_t)(r + (long long)u * BN_RY) * C + col, o);
+    }
+  }
+}
+
+// dgamma, dbeta and the dx coefficients  dx = k0 * g + k1 * x + k2
+__global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_bwd_kernel(const float* __restrict__ ws, int S, int C, long long M,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ coef) {
+  float A, B;
+  bn_sum_partials(ws, S, C, blockIdx.x, A, B);
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const float is = invstd[c], mu = mean[c];
+    const float dg = B * is;                     // sum g * xhat
+    dgamma[c] = dg;
+    dbeta[c] = A;
+    const float k0 = gamma[c] * is;
+    const float inv_m = 1.f / (float)M;
+    const float k1 = -k0 * is * dg * inv_m;      // multiplies (x - mean)
+    coef[(size_t)c * 3 + 0] = k0;
+    coef[(size_t)c * 3 + 1] = k1;
+    coef[(size_t)c * 3 + 2] = -k0 * A * inv_m - k1 * mu;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                           const float* __restrict__ coef, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, long long M, int C, int rows_per_split,
+                                                           int relu, T* __restrict__ dx, T* __restrict__ dres) {
+  const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
+  const long long r0 = (long long)blockIdx.y * rows_per_split;
+  const long long r1 = (r0 + rows_per_split < M) ? r0 + rows_per_split : M;
+  const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
+  float k0[8], k1[8], k2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    k0[i] = coef[(col + i) * 3 + 0];
+    k1[i] = coef[(col + i) * 3 + 1];
+    k2[i] = coef[(col + i) * 3 + 2];
+  }
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sc[i] = 0.f; sh[i] = 0.f; }
+  if (relu == 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = gamma[col + i] * invstd[col + i];
+      sh[i] = beta[col + i] - mean[col + i] * sc[i];
+    }
+  }
+  for (long long r = r0 + ry; r < r1; r += BN_UNROLL * BN_RY) {
+    float vx[BN_UNROLL][8], vg[BN_UNROLL][8], vy[BN_UNROLL][8];
+    bool ok[BN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      const long long rr = r + (long long)u * BN_RY;
+      ok[u] = rr < r1;
+      const size_t off = (size_t)(ok[u] ? rr : r) * C + col;
+      load8(x + off, vx[u]);
+      load8(dy + off, vg[u]);
+      if (relu == 1) load8(y + off, vy[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_UNROLL; ++u) {
+      float o[8], g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        g[i] = vg[u][i];
+        if (relu == 1) g[i] = vy[u][i] <= 0.f ? 0.f : g[i];
+        if (relu == 2) g[i] = fmaf(vx[u][i], sc[i], sh[i]) <= 0.f ? 0.f : g[i];
+        o[i] = fmaf(k0[i], g[i], fmaf(k1[i], vx[u][i], k2[i]));
+      }
+      if (ok[u]) {
+        const size_t off = (size_t)(r + (long long)u * BN_RY) * C + col;
+        store8(dx + off, o);
+        if (dres) store8(dres + off, g);
+      }
+    }
+  }
+}
+
+static inline int bn_splits(long long M, int C, int target_blocks, int cap) {
+  const int groups = C / 64;
+  long long s = (target_blocks + groups - 1) / groups;
+  const long long by_rows = (M + 63) / 64;          // at least 64 rows per block
+  if (s > by_rows) s = by_rows;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+static inline int bn_rows_per_split(long long M, int S) {
+  const long long r = (M + S - 1) / S;
+  return (int)((r + BN_RY - 1) / BN_RY * BN_RY);
+}
+
+template <typename T>
+static int run_bn_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* rmean, float* rvar,
+                      float momentum, float eps, int relu, long long M, int C, void* y, float* save_mean, float* save_invstd,
+                      float* ws, hipStream_t st) {
+  const int S = bn_splits(M, C, 1024, 512), rps = bn_rows_per_split(M, S);
+  const int S_eff = (int)((M + rps - 1) / rps);
+  hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
+                     (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, rps, 0, ws);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, M, eps, momentum,
+                     rmean, rvar, save_mean, save_invstd);
+  const int S2 = bn_splits(M, C, 2048, 4096), rps2 = bn_rows_per_split(M, S2);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((M + rps2 - 1) / rps2)), dim3(BN_THREADS), 0, st, (const T*)x,
+                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, M, C, rps2, relu, (T*)y);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+template <typename T>
+static int run_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                      int relu, long long M, int C, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
+  const int S = bn_splits(M, C, 1024, 512), rps = bn_rows_per_split(M, S);
+  const int S_eff = (int)((M + rps - 1) / rps);
+  float* coef = ws + (size_t)2 * S_eff * C;
+  hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
+                     (const T*)y, mean, invstd, gamma, beta, M, C, rps, relu, ws);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, M, gamma, mean,
+                     invstd, dgamma, dbeta, coef);
+  const int S2 = bn_splits(M, C, 2048, 4096), rps2 = bn_rows_per_split(M, S2);
+  hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((M + rps2 - 1) / rps2)), dim3(BN_THREADS), 0, st, (const T*)dy,
+                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, M, C, rps2, relu, (T*)dx, (T*)dres);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+}  // namespace td
+
+extern "C" long long td_bn_workspace_floats(long long M, int C) {
+  if (M <= 0 || C <= 0 || C % 64 != 0) return 0;
+  const int S = td::bn_splits(M, C, 1024, 512);
+  return (long long)2 * S * C + (long long)3 * C;
+}
+
+extern "C" int td_bn_fwd(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int relu, long long M, int C,
+                         void* y, float* save_mean, float* save_invstd, float* workspace, td_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0) return TD_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TD_ERR_BAD_ARG;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_fwd<__hip_bfloat16>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, M, C, y,
+                                          save_mean, save_invstd, workspace, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_fwd<float>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, M, C, y, save_mean,
+                                 save_invstd, workspace, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta, const float* save_mean,
+                         const float* save_invstd, int relu, long long M, int C, void* dx, void* dresidual, float* dgamma,
+                         float* dbeta, float* workspace, td_stream_t stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0)
+    return TD_ERR_BAD_ARG;
+  if (relu < 0 || relu > 1) return TD_ERR_BAD_ARG;
+  if (relu && !y && (!beta || dresidual)) return TD_ERR_BAD_ARG;   // the mask comes from y, or is recomputed from x (no residual)
+  if (relu && !y) relu = 2;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_bwd<__hip_bfloat16>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, C, dx, dresidual, dgamma, dbeta,
+                                          workspace, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_bwd<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, C, dx, dresidual, dgamma, dbeta, workspace,
+                                 (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}

@@ -18,21 +18,64 @@ import torch.nn.functional as F
 
 
 
+FUSED_BN_OFF = bool(os.environ.get("TD_NO_FUSED_BN"))
+
+
+def _ops():
+    from tripled_amd import ops
+    return ops
+
+
 class BatchNorm(nn.BatchNorm2d):
     """nn.BatchNorm2d with the per-layer ``num_batches_tracked += 1`` taken out of forward().  The
     counter is not used by the computation when momentum is a number (0.1 here); bumping 252 of them
     one tiny kernel at a time costs ~1 ms per step, so ``bump_batch_counters(model)`` advances all of
     them with a single multi-tensor add once per training forward.  Same parameters/buffers/state_dict
-    keys and the same outputs as nn.BatchNorm2d."""
+    keys and the same outputs as nn.BatchNorm2d.
+
+    On channels_last HIP activations (C % 64 == 0) training-mode normalisation runs in the hand-written
+    kernels of csrc/td_bn.hip; ``fused()`` additionally folds the residual add and ReLU that follow the
+    normalisation in every ResNet block into the same pass (TD_NO_FUSED_BN=1 restores ATen/MIOpen)."""
 
     _pending = 0
+
+    def _hip_ok(self, x):
+        if not (x.is_cuda and self.training and self.track_running_stats and self.momentum is not None
+                and self.affine) or FUSED_BN_OFF:
+            return False
+        return _ops().batchnorm_act_supported(x, self.weight)
 
     def forward(self, x):
         if self.training and self.track_running_stats and self.momentum is not None:
             self._pending += 1
+            if self._hip_ok(x):
+                return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                         self.momentum, self.eps)
             return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
                                 self.momentum, self.eps)
         return super().forward(x)
+
+    def fused(self, x, residual=None, relu=True):
+        """bn(x) [+ residual] [-> relu] -- one HIP apply pass on channels_last CUDA activations in training."""
+        if self._hip_ok(x):
+            self._pending += 1
+            return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                     self.momentum, self.eps, residual=residual, relu=relu)
+        return _plain_bn_act(self, x, residual, relu)
+
+
+def _plain_bn_act(bn, x, residual, relu):
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """bn -> [+ residual] -> [relu] for any normalisation module (SyncBatchNorm after conversion included)."""
+    if isinstance(bn, BatchNorm):
+        return bn.fused(x, residual, relu)
+    return _plain_bn_act(bn, x, residual, relu)
 
 
 def bump_batch_counters(model):
@@ -81,11 +124,11 @@ class BasicBlock(nn.Module):
         self.use_residual = use_residual
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
+        y = bn_act(self.bn1, self.conv1(x))
+        shortcut = None
         if self.use_residual:
-            y = y + (x if self.downsample is None else self.downsample(x))
-        return self.relu(y)
+            shortcut = x if self.downsample is None else self.downsample(x)
+        return bn_act(self.bn2, self.conv2(y), shortcut)
 
 
 class Bottleneck(nn.Module):
@@ -105,11 +148,9 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        y = y + (x if self.downsample is None else self.downsample(x))
-        return self.relu(y)
+        y = bn_act(self.bn1, self.conv1(x))
+        y = bn_act(self.bn2, self.conv2(y))
+        return bn_act(self.bn3, self.conv3(y), x if self.downsample is None else self.downsample(x))
 
 
 class ResNet(nn.Module):
@@ -143,7 +184,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*stage)
 
     def stem(self, x):
-        return self.relu(self.bn1(self.conv1(x)))
+        return bn_act(self.bn1, self.conv1(x))
 
     def pyramid(self, x, extra=None):
         """The five feature maps every encoder here exposes (strides 2, 4, 8, 16, 32);

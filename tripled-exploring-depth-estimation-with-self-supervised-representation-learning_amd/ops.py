@@ -212,6 +212,68 @@ def maxpool5(x):
     return _MaxPool5.apply(x)
 
 
+class _BatchNormAct(torch.autograd.Function):
+    """F.batch_norm(training=True) [+ residual] [-> relu] on a channels_last tensor, three launches each way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu):
+        lib = native.load()
+        N, C, H, W = x.shape
+        M = N * H * W
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.td_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        native.check(lib.td_bn_fwd(_raw(x), _raw(residual) if residual is not None else None, native.DTYPE_CODES[x.dtype],
+                                   native.ptr(weight), native.ptr(bias),
+                                   native.ptr(running_mean) if running_mean is not None else None,
+                                   native.ptr(running_var) if running_var is not None else None,
+                                   float(momentum), float(eps), int(relu), M, C, _raw(y), native.ptr(mean),
+                                   native.ptr(invstd), native.ptr(ws), native.stream()), "td_bn_fwd")
+        # the ReLU mask is re-derived from x in backward unless a residual went into the pre-activation
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, mean, invstd)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = native.load()
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        M = N * H * W
+        if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        # relu + residual: the masked gradient is a second output; without relu the residual gradient is dy itself
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if (ctx.has_res and ctx.relu) else None
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.td_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        native.check(lib.td_bn_bwd(_raw(dy), _raw(x), _raw(y) if y is not None else None, native.DTYPE_CODES[x.dtype],
+                                   native.ptr(weight), native.ptr(bias), native.ptr(mean), native.ptr(invstd), int(ctx.relu), M, C,
+                                   _raw(dx), _raw(dres) if dres is not None else None, native.ptr(dgamma),
+                                   native.ptr(dbeta), native.ptr(ws), native.stream()), "td_bn_bwd")
+        if ctx.has_res and not ctx.relu:
+            dres = dy
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None
+
+
+def batchnorm_act_supported(x, weight):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 64 == 0
+            and weight is not None and weight.dtype == torch.float32
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def batchnorm_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
+    """Training-mode BatchNorm2d + optional residual add + optional ReLU (reference: resnet.py:30-49, 66-86)."""
+    if not batchnorm_act_supported(x, weight):
+        raise native.NativeLibraryError("batchnorm_act needs a channels_last f32/bf16 HIP tensor with C % 64 == 0")
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
+
+
 def edge_weights(img_at_scale, a, scale6):
     """Per-pixel, per-term image weights scale_k * exp(-a * mean_c |d_k I|) -> [B,6,h,w] (no gradient)."""
     import ctypes
