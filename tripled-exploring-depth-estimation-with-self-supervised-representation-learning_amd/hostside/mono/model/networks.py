@@ -335,6 +335,13 @@ class PoseDecoder(nn.Module):
 # decoder building blocks (reference: layers.py:110-215)
 
 def upsample(x):
+    """x2 nearest-neighbour (reference: layers.py upsample).  CUDA autocast lists upsample_nearest2d as an
+    fp32 op: a bf16 activation would come back as float32 and drag the following reflection pad and the
+    cast in front of the next convolution through twice the bytes.  Nearest sampling is exact in any dtype,
+    so it runs outside autocast in the activation's own dtype."""
+    if x.is_cuda and torch.is_autocast_enabled():
+        with torch.autocast("cuda", enabled=False):
+            return F.interpolate(x, scale_factor=2, mode="nearest")
     return F.interpolate(x, scale_factor=2, mode="nearest")
 
 
