@@ -288,6 +288,13 @@ def main():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if not args.no_graph and (world == 1 or split_graph):
+        # N > 1: every collective of the warm-up has completed (synchronize above) and the ranks line up before
+        # capturing; "thread_local" keeps the process group's watchdog thread (event queries) from
+        # invalidating the capture -- no collective is issued inside either graph
+        mode = "global" if world == 1 else "thread_local"
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
         try:
             graph = torch.cuda.CUDAGraph()
             if not split_graph:
@@ -295,10 +302,10 @@ def main():
                     step()
                 graph.replay()
             else:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=mode):
                     step.forward_backward()
                 graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b):
+                with torch.cuda.graph(graph_b, capture_error_mode=mode):
                     step.update()
                 graph.replay()
                 step.sync()
@@ -384,8 +391,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        # the result line is out; a peer that tears its sockets down first must not turn into a failed run
+        try:
+            dist.barrier()
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001
+            print("rank %d: teardown: %s" % (rank, e), file=sys.stderr)
 
 
 if __name__ == "__main__":

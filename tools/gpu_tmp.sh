@@ -1,8 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-run() { python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline $2 > gpurun_out/$1.log 2>&1
-  echo $1 $(tail -1 gpurun_out/$1.log | grep -o 'ms_per_step": [0-9.]*\|final_loss": [0-9.]*'); }
-run nofind "--miopen-find off"
-run find
-run find2
+export TD_DIST_BACKEND=gloo
+timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --miopen-find off --no-roofline > gpurun_out/n2_gloo.log 2>&1
+tail -2 gpurun_out/n2_gloo.log | cut -c1-600
