@@ -103,3 +103,63 @@ def _worker(rank, world, port, out_dir):
 def test_two_rank_gradient_sync(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def _worker_deferred(rank, world, port):
+    """The benchmark's N > 1 form: no autograd hooks, all buckets reduced after backward (between two HIP
+    graphs on the GPU), and the flat mixed-precision store's own all-reduce."""
+    sys.path.insert(0, ROOT)
+    import tripled_amd  # noqa: F401
+    from mmcv.parallel import MMDistributedDataParallel
+    from tripled_amd.flat_amp import FlatMixedPrecision
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    net = Net()
+    ddp = MMDistributedDataParallel(net, bucket_cap_mb=0.0002, find_unused_parameters=True, overlap=False)
+    g = torch.Generator().manual_seed(11 + rank)
+    x, y = torch.randn(5, 8, generator=g), torch.randn(5, 1, generator=g)
+    ddp.train()
+    (ddp(x) - y).pow(2).mean().backward()
+    local = Net()
+    local.load_state_dict(net.state_dict())
+    (local(x) - y).pow(2).mean().backward()
+    mine = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    for (n, p), q in zip(net.named_parameters(), local.parameters()):      # nothing exchanged yet
+        if q.grad is not None:
+            assert torch.allclose(mine[n], q.grad, atol=1e-6), n
+    ddp.reducer.allreduce_all()
+    for (n, p), q in zip(net.named_parameters(), local.parameters()):
+        if q.grad is None:
+            continue
+        t = q.grad.clone()
+        dist.all_reduce(t)
+        t /= world
+        assert torch.allclose(p.grad, t, atol=1e-6), n
+
+    # FlatMixedPrecision: gather -> bucketed all-reduce of the flat buffer -> clip + Adam keeps replicas identical
+    torch.manual_seed(9)
+    conv = nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 2, 1))
+    flat = FlatMixedPrecision(conv, lr=1e-2, max_norm=1.0, bucket_bytes=256)
+    assert len(flat.buckets) > 1
+    img = torch.randn(2, 3, 6, 6, generator=g)
+    for _ in range(2):
+        flat.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            conv(img).float().square().mean().backward()
+        flat.collect()
+        local_g = flat.flat_g.clone()
+        flat.allreduce()
+        want = local_g.clone()
+        dist.all_reduce(want)
+        assert torch.allclose(flat.flat_g, want / world, atol=1e-7)
+        flat.step()
+    parts = [torch.zeros_like(flat.flat_w) for _ in range(world)]
+    dist.all_gather(parts, flat.flat_w)
+    assert torch.equal(parts[0], parts[1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_deferred_allreduce_and_flat_store():
+    mp.spawn(_worker_deferred, args=(2, _free_port()), nprocs=2, join=True)
