@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1; echo prof rc=$?
 f=$(ls /tmp/prof_bench/*/*kernel_stats.csv | head -1)
-head -1 $f > $R/gpurun_out/bench_kernel_stats_td.csv; grep "td::" $f >> $R/gpurun_out/bench_kernel_stats_td.csv
+head -1 $f > $R/gpurun_out/bench_kernel_stats_td.csv; grep -E "(^\"|[^s])td::" $f >> $R/gpurun_out/bench_kernel_stats_td.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc_$pass -- python3 $R/tools/kernel_bench.py --iters 3 --only identity,fwd,bwd > $R/gpurun_out/pmc_$pass.log 2>&1; echo "$pass rc=$?"
 done
