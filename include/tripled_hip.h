@@ -187,6 +187,18 @@ int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, 
                     void* grad_in, td_stream_t stream);
 
 /*
+ * Channel concatenation of the DepthDecoder stages on channels-last activations
+ * (mono/model/mono_fm_joint/depth_decoder.py:89-103, torch.cat((reduce(l), x, disp), 1)):
+ *   out[pix, :] = [a[pix, :C0], b[pix, :C1], tail[pix, :C2], 0 ... 0]   with C0 + C1 + 8 output channels,
+ *   C0 % 8 == C1 % 8 == 0, 1 <= C2 <= 8; all tensors [npix, C] row-major (NHWC), dtype f32 or bf16.
+ * td_join_bwd writes the three slices of grad_out (the padding's gradient is dropped).
+ */
+int td_join_fwd(const void* a, const void* b, const void* tail, int dtype, long long npix, int C0, int C1, int C2,
+                void* out, td_stream_t stream);
+int td_join_bwd(const void* grad_out, int dtype, long long npix, int C0, int C1, int C2, void* grad_a, void* grad_b,
+                void* grad_tail, td_stream_t stream);
+
+/*
  * Training-mode BatchNorm2d on channels-last activations with the residual add and ReLU of the ResNet
  * blocks fused in (mono/model/mono_fm_joint/resnet.py:30-49 BasicBlock.forward, :66-86
  * Bottleneck.forward; F.batch_norm(training=True) semantics: biased batch variance for the output,

@@ -74,3 +74,20 @@ def test_resnet_block_uses_fused_bn():
     finally:
         networks.FUSED_BN_OFF = False
     assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 5, 7, 1), (3, 256, 256, 12, 20, 1), (1, 8, 24, 3, 4, 5)])
+def test_join_channels_matches_cat(shape, dtype):
+    """DepthDecoder stage input (depth_decoder.py:89-103): cat + zero padding to a multiple of 8 channels."""
+    N, C0, C1, H, W, C2 = shape
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    mk = lambda c: cl(torch.randn(N, c, H, W, device="cuda").to(dtype)).requires_grad_(True)
+    a, b, t = mk(C0), mk(C1), mk(C2)
+    out = ops.join_channels(a, b, t)
+    ref = torch.cat((a, b, t, a.new_zeros(N, 8 - C2, H, W)), 1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    g = cl(torch.randn_like(ref))
+    out.backward(g)
+    assert torch.equal(a.grad, g[:, :C0]) and torch.equal(b.grad, g[:, C0:C0 + C1])
+    assert torch.equal(t.grad, g[:, C0 + C1:C0 + C1 + C2])

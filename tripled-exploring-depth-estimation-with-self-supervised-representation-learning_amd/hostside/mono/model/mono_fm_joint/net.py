@@ -13,6 +13,15 @@ from .layers import SSIM, Backproject, Project
 from .. import hotpath
 
 
+def resize_bilinear(img, size):
+    """F.interpolate(img, size, mode="bilinear", align_corners=False).  When ``img`` already has that size the
+    sampling positions are the pixel centres (scale 1, lambda 0), i.e. the op is a bit-exact identity, and
+    the copy is skipped (the KITTI configs feed 192x640 images to a 192x640 pose network)."""
+    if list(img.shape[-2:]) == list(size):
+        return img
+    return F.interpolate(img, size, mode="bilinear", align_corners=False)
+
+
 @MONO.register_module
 class mono_fm_joint(nn.Module):
     def __init__(self, options):
@@ -213,8 +222,7 @@ class mono_fm_joint(nn.Module):
         """net.py:164-179: pose net on [previous, current] pairs resized to 192x640."""
         outputs = {}
         if pose_feats is None:
-            pose_feats = {f: F.interpolate(inputs["color_aug", f, 0], [192, 640], mode="bilinear",
-                                           align_corners=False) for f in self.opt.frame_ids}
+            pose_feats = {f: resize_bilinear(inputs["color_aug", f, 0], [192, 640]) for f in self.opt.frame_ids}
         for f in self.opt.frame_ids[1:]:
             if f == "s":
                 continue

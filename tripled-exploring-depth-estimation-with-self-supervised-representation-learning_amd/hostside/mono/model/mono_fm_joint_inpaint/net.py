@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import MONO
-from ..mono_fm_joint.net import mono_fm_joint
+from ..mono_fm_joint.net import mono_fm_joint, resize_bilinear
 from ..networks import ColorDecoder, Conv1x1, DepthDecoder, Encoder, IdentityPartial
 from .color_conversions import rgb2lab
 
@@ -194,10 +194,8 @@ class mono_fm_joint_inpaint_disentangle(mono_fm_joint_inpaint):
                          for i, split in enumerate(opt.disentangle_layers)]
         outputs = self.ColorDecoder(color_emb, outputs, skip_layers=opt.color_skip_layers)
         if opt.get("use_pfp", False):
-            feats = {f: F.interpolate(inputs["color_aug", f, 0], [192, 640], mode="bilinear", align_corners=False)
-                     for f in opt.frame_ids[1:]}
-            feats[0] = F.interpolate(outputs[("auto_res_img", 0, 0)], [192, 640], mode="bilinear",
-                                     align_corners=False)
+            feats = {f: resize_bilinear(inputs["color_aug", f, 0], [192, 640]) for f in opt.frame_ids[1:]}
+            feats[0] = resize_bilinear(outputs[("auto_res_img", 0, 0)].float(), [192, 640])
             outputs.update(self.predict_poses(inputs, feats))
         else:
             outputs.update(self.predict_poses(inputs))

@@ -515,6 +515,8 @@ class DepthDecoder(nn.Module):
             parts = [r, x, d.to(x.dtype)]
             c = sum(p.shape[1] for p in parts)
             if x.is_cuda and c % 8 and x.dtype == torch.bfloat16 and not os.environ.get("TD_NO_CHANNEL_PAD"):
+                if _round8(c) == r.shape[1] + x.shape[1] + 8 and _ops().join_channels_supported(*parts):
+                    return _ops().join_channels(*parts)        # one HIP pass (ATen cat: 528 us at 48x160)
                 # 513 -> 520 zero channels: see Conv3x3
                 parts.append(x.new_zeros(x.shape[0], _round8(c) - c, x.shape[2], x.shape[3]))
             return torch.cat(parts, 1)

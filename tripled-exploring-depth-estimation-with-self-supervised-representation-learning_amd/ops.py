@@ -212,6 +212,47 @@ def maxpool5(x):
     return _MaxPool5.apply(x)
 
 
+class _JoinChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, tail):
+        lib = native.load()
+        N, C0, H, W = a.shape
+        C1, C2 = b.shape[1], tail.shape[1]
+        out = torch.empty((N, C0 + C1 + 8, H, W), device=a.device, dtype=a.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_join_fwd(_raw(a), _raw(b), _raw(tail), native.DTYPE_CODES[a.dtype], N * H * W, C0, C1, C2,
+                                     _raw(out), native.stream()), "td_join_fwd")
+        ctx.dims = (N, C0, C1, C2, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        N, C0, C1, C2, H, W = ctx.dims
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        mk = lambda c: torch.empty((N, c, H, W), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+        ga, gb, gt = mk(C0), mk(C1), mk(C2)
+        native.check(lib.td_join_bwd(_raw(g), native.DTYPE_CODES[g.dtype], N * H * W, C0, C1, C2, _raw(ga), _raw(gb),
+                                     _raw(gt), native.stream()), "td_join_bwd")
+        return ga, gb, gt
+
+
+def join_channels_supported(a, b, tail):
+    cl = lambda t: t.is_contiguous(memory_format=torch.channels_last)
+    return (a.is_cuda and a.dim() == 4 and a.dtype in native.DTYPE_CODES and b.dtype == a.dtype and tail.dtype == a.dtype
+            and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and 1 <= tail.shape[1] <= 8
+            and a.shape[0] == b.shape[0] == tail.shape[0] and a.shape[2:] == b.shape[2:] == tail.shape[2:]
+            and cl(a) and cl(b) and cl(tail))
+
+
+def join_channels(a, b, tail):
+    """torch.cat((a, b, tail, zeros), 1) up to C0 + C1 + 8 channels on channels_last HIP tensors
+    (reference: depth_decoder.py:89-103 plus the channel-alignment padding of Conv3x3)."""
+    if not join_channels_supported(a, b, tail):
+        raise native.NativeLibraryError("join_channels needs channels_last f32/bf16 HIP tensors, C0 % 8 == C1 % 8 == 0, C2 <= 8")
+    return _JoinChannels.apply(a, b, tail)
+
+
 class _BatchNormAct(torch.autograd.Function):
     """F.batch_norm(training=True) [+ residual] [-> relu] on a channels_last tensor, three launches each way."""
 
