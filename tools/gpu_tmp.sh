@@ -1,6 +1,8 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-export TD_DIST_BACKEND=gloo
-timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --miopen-find off --no-roofline > gpurun_out/n2_gloo.log 2>&1
-tail -2 gpurun_out/n2_gloo.log | cut -c1-600
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/b.log 2>&1
+tail -1 gpurun_out/b.log
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --h2d > gpurun_out/b_h2d.log 2>&1
+tail -1 gpurun_out/b_h2d.log | grep -o 'ms_per_step": [0-9.]*'
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log
