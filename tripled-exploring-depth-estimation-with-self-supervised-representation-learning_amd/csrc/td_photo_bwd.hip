@@ -10,11 +10,14 @@
 //   3. chains through the bilinear sampler, the projection and the depth.
 // No LDS, no barriers, no atomics: d_up is written once per pixel per frame (first frame stores,
 // later frames add), dL/dP is accumulated in registers and written once per wave.
+// The library is built with -ffp-contract=off for the forward's sake (SSIM variances).  The adjoint has no such
+// cancellation, so this translation unit lets the compiler fuse multiply-adds (-4 % time; gradients move by ~1 ulp).
+#pragma clang fp contract(fast)
 #include "td_common.h"
 
 namespace td {
 
-constexpr int BS_ROWS = 8;        // gradient rows per wave task
+// gradient rows per wave task: chosen per shape by pick_rows() (PhotoBwdArgs::rows)
 constexpr int BS_COLS = 62;       // gradient columns per wave task (1-column halo on both sides)
 constexpr int BS_WAVES = 4;
 
@@ -32,7 +35,7 @@ struct PhotoBwdArgs {
   float* dP_partial;
   int B, H, W, hs, ws;
   int n_ident;            // candidates preceding the warped ones (n_src when automasking, else 0)
-  int nstrips, nchunks, ntasks, blocks_per_xcd;
+  int nstrips, nchunks, ntasks, blocks_per_xcd, rows;
   float inv_count;
   float min_disp, disp_range;
 };
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
   const int H = a.H, W = a.W;
   const unsigned plane = (unsigned)(H * W);
   const int x = strip * BS_COLS - 1 + lane;          // padded-domain column of this lane
-  const int y0 = chunk * BS_ROWS;
+  const int y0 = chunk * a.rows;
   const bool col_in = x >= 0 && x < W;
   const bool col_out = lane >= 1 && lane <= BS_COLS && col_in;
   const int xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
   const float g = a.gscale[0] * a.inv_count;
   const float g_ssim = g * 0.85f / 3.f / 9.f, g_l1 = g * 0.15f / 3.f;
   const float sx_scale = (float)W / (float)(W - 1), sy_scale = (float)H / (float)(H - 1);   // d ix / d u, d iy / d v
-  constexpr int NK = BS_ROWS + 2;
+  const int NK = a.rows + 2;
 
 #pragma unroll 1
   for (int f = 0; f < NS; ++f) {
@@ -209,9 +212,10 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
   }
 }
 
-static int bwd_tasks(int B, int H, int W, int* nstrips, int* nchunks) {
+static int bwd_tasks(int B, int H, int W, int* nstrips, int* nchunks, int* rows) {
   *nstrips = (W + BS_COLS - 1) / BS_COLS;
-  *nchunks = (H + BS_ROWS - 1) / BS_ROWS;
+  *rows = pick_rows(B * (*nstrips), H, 2, 1, 8, 64);
+  *nchunks = (H + *rows - 1) / *rows;
   return B * (*nstrips) * (*nchunks);
 }
 
@@ -231,7 +235,7 @@ static int run_bwd(const float* tgt, const float* const* src, const float* disp,
   const double lo = 1.0 / (double)max_depth, hi = 1.0 / (double)min_depth;
   a.min_disp = (float)lo;
   a.disp_range = (float)(hi - lo);
-  a.ntasks = bwd_tasks(B, H, W, &a.nstrips, &a.nchunks);
+  a.ntasks = bwd_tasks(B, H, W, &a.nstrips, &a.nchunks, &a.rows);
   const int blocks = (a.ntasks + BS_WAVES - 1) / BS_WAVES;
   a.blocks_per_xcd = (blocks + 7) / 8;
   hipLaunchKernelGGL((photo_bwd_kernel<NS>), dim3(a.blocks_per_xcd * 8), dim3(BS_WAVES * 64), 0, st, a);
@@ -319,15 +323,15 @@ extern "C" int td_photo_bwd(const float* tgt, const float* const* src, int n_src
 
 extern "C" int td_photo_bwd_num_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  int ns, nc;
-  return td::bwd_tasks(B, H, W, &ns, &nc);
+  int ns, nc, rows;
+  return td::bwd_tasks(B, H, W, &ns, &nc, &rows);
 }
 
 extern "C" int td_reduce_dP(const float* dP_partial, int n_src, int B, int H, int W, float* dP,
                             td_stream_t stream) {
   if (!dP_partial || !dP || n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || H <= 0 || W <= 0) return TD_ERR_BAD_ARG;
-  int ns, nc;
-  td::bwd_tasks(1, H, W, &ns, &nc);
+  int ns, nc, rows;
+  td::bwd_tasks(B, H, W, &ns, &nc, &rows);        // the task tiling depends on the whole launch shape
   const int bps = ns * nc;
   hipLaunchKernelGGL(td::reduce_dP_kernel, dim3(n_src * 12, B), dim3(64), 0, (hipStream_t)stream,
                      dP_partial, n_src, B, bps, dP);

@@ -13,7 +13,7 @@
 
 namespace td {
 
-constexpr int FS_ROWS = 8;        // output rows per wave task
+// output rows per wave task: chosen per shape by pick_rows() (PhotoFwdArgs::rows, always even)
 constexpr int FS_COLS = 62;       // output columns per wave task
 constexpr int FS_WAVES = 4;       // independent wave tasks per 256-thread block
 
@@ -33,7 +33,7 @@ struct PhotoFwdArgs {
   float* idloss_out;   // identity mode only
   float* coef;         // [B,9,H,W] SSIM-adjoint coefficients of the selected warped frame (nullable)
   int B, H, W, hs, ws;
-  int nstrips, nchunks, ntasks, blocks_per_xcd;
+  int nstrips, nchunks, ntasks, blocks_per_xcd, rows;
   float min_disp, disp_range;
 };
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   const unsigned plane = (unsigned)(H * W);
   const int x = strip * FS_COLS - 1 + lane;          // padded-domain column of this lane
   const int qx = reflect1(x, W);
-  const int y0 = chunk * FS_ROWS;
+  const int y0 = chunk * a.rows;
   const bool col_out = lane >= 1 && lane <= FS_COLS && x < W;
   const int xo = x < W ? (x < 0 ? 0 : x) : W - 1;    // clamped column for prefetching per-pixel inputs
 
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
 #pragma unroll
       for (int c = 0; c < 3; ++c) xw[f][c] = IDENT ? cur.xv[f][c] : blend_taps(cur.tv[f][c], cur.taps[f]);
     const int r = y0 - 1 + k;
-    if (KEEP && !IDENT && k >= 1 && k <= FS_ROWS && r < H && col_out) {
+    if (KEEP && !IDENT && k >= 1 && k <= a.rows && r < H && col_out) {
 #pragma unroll
       for (int f = 0; f < NS; ++f)
 #pragma unroll
@@ -269,9 +269,8 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
     }
   };
 
-  // ---- two-deep software pipeline over NK = FS_ROWS + 2 rows, ping-pong register sets ----
-  constexpr int NK = FS_ROWS + 2;
-  static_assert(NK % 2 == 0 && NK >= 6, "row pipeline is unrolled by two");
+  // ---- two-deep software pipeline over NK = rows + 2 rows (even, >= 6: the loop is unrolled by two), ping-pong register sets ----
+  const int NK = a.rows + 2;
   RowLoads<NS> LA, LB;
   DispTaps DA, DB;
   if (!IDENT) {
@@ -305,15 +304,16 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   }
 }
 
-static int fwd_tasks(int B, int H, int W, int* nstrips, int* nchunks) {
+static int fwd_tasks(int B, int H, int W, int* nstrips, int* nchunks, int* rows) {
   *nstrips = (W + FS_COLS - 1) / FS_COLS;
-  *nchunks = (H + FS_ROWS - 1) / FS_ROWS;
+  *rows = pick_rows(B * (*nstrips), H, 2, 2, 8, 64);      // even
+  *nchunks = (H + *rows - 1) / *rows;
   return B * (*nstrips) * (*nchunks);
 }
 
 template <int NS, int MODE, bool KEEP, bool COEF>
 static int launch_fwd(PhotoFwdArgs<NS>& a, hipStream_t st) {
-  a.ntasks = fwd_tasks(a.B, a.H, a.W, &a.nstrips, &a.nchunks);
+  a.ntasks = fwd_tasks(a.B, a.H, a.W, &a.nstrips, &a.nchunks, &a.rows);
   const int blocks = (a.ntasks + FS_WAVES - 1) / FS_WAVES;
   a.blocks_per_xcd = (blocks + 7) / 8;
   hipLaunchKernelGGL((photo_fwd_kernel<NS, MODE, KEEP, COEF>), dim3(a.blocks_per_xcd * 8), dim3(FS_WAVES * 64), 0, st, a);
@@ -367,8 +367,8 @@ static int run_fwd(const float* tgt, const float* const* src, const float* disp,
 
 extern "C" int td_photo_num_blocks(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  int ns, nc;
-  return td::fwd_tasks(B, H, W, &ns, &nc);
+  int ns, nc, rows;
+  return td::fwd_tasks(B, H, W, &ns, &nc, &rows);
 }
 
 static int dispatch_fwd(const float* tgt, const float* const* src, int n_src, const float* disp,

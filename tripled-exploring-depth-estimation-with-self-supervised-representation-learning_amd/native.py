@@ -73,7 +73,7 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("TD_HIP_LIB") or LIB_PATH      # TD_HIP_LIB: alternative build of the same ABI
     if not os.path.exists(path):
         raise NativeLibraryError(
             "libtripled_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
