@@ -210,15 +210,19 @@ int td_join_bwd(const void* grad_out, int dtype, long long npix, int C0, int C1,
  *   backward: g = dy * [y > 0] (relu; with y == NULL and no residual the mask is recomputed from x, gamma, beta,
  *             save_mean, save_invstd exactly as the forward formed it) ; dbeta = sum g ; dgamma = sum g * xhat ;
  *             dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M) ; dresidual = g
- *   workspace: td_bn_workspace_floats(M, C) floats (partial sums + coefficients; contents undefined on return).
+ *   groups: the M rows are `groups` consecutive equal ranges with separate batch statistics (save_mean /
+ *           save_invstd are [groups, C]); the running statistics receive one momentum update per group, in
+ *           order, and dgamma / dbeta are summed over the groups -- i.e. exactly `groups` separate calls on the
+ *           stacked passes of one network over different frames (pose pairs, source-frame features).
+ *   workspace: td_bn_workspace_floats(M, groups, C) floats (partial sums + coefficients; contents undefined on return).
  */
-long long td_bn_workspace_floats(long long M, int C);
+long long td_bn_workspace_floats(long long M, int groups, int C);
 int td_bn_fwd(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
-              float* running_mean, float* running_var, float momentum, float eps, int relu, long long M, int C,
-              void* y, float* save_mean, float* save_invstd, float* workspace, td_stream_t stream);
+              float* running_mean, float* running_var, float momentum, float eps, int relu, long long M, int groups,
+              int C, void* y, float* save_mean, float* save_invstd, float* workspace, td_stream_t stream);
 int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta, const float* save_mean,
-              const float* save_invstd, int relu, long long M, int C, void* dx, void* dresidual, float* dgamma,
-              float* dbeta, float* workspace, td_stream_t stream);
+              const float* save_invstd, int relu, long long M, int groups, int C, void* dx, void* dresidual,
+              float* dgamma, float* dbeta, float* workspace, td_stream_t stream);
 
 /*
  * Edge-aware regulariser on C-channel feature maps: get_feature_regularization_loss,

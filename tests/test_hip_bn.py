@@ -91,3 +91,37 @@ def test_join_channels_matches_cat(shape, dtype):
     out.backward(g)
     assert torch.equal(a.grad, g[:, :C0]) and torch.equal(b.grad, g[:, C0:C0 + C1])
     assert torch.equal(t.grad, g[:, C0 + C1:C0 + C1 + C2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
+def test_grouped_batchnorm_equals_separate_passes(relu, with_res, dtype):
+    """groups=G on a stacked batch == G separate calls (statistics per pass, running stats updated in order,
+    weight gradients summed): the pose pairs / source-frame features of mono_fm_joint/net.py:172-178, :221."""
+    dev, G, N, C, H, W = torch.device("cuda"), 3, 4, 128, 9, 13
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(3)
+    x = cl((torch.randn(G * N, C, H, W, generator=g) * torch.linspace(0.5, 2.0, G).repeat_interleave(N)[:, None, None, None]).to(dev).to(dtype))
+    res = cl(torch.randn(G * N, C, H, W, generator=g).to(dev).to(dtype)) if with_res else None
+    dy = cl(torch.randn(G * N, C, H, W, generator=g).to(dev).to(dtype))
+    w, b = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+
+    def run(groups):
+        xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rs = res.clone().requires_grad_(True) if with_res else None
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        if groups > 1:
+            y = ops.batchnorm_act(xs, ws, bs, rm, rv, 0.1, 1e-5, residual=rs, relu=relu, groups=groups)
+        else:
+            y = torch.cat([ops.batchnorm_act(cl(xs[i * N:(i + 1) * N]), ws, bs, rm, rv, 0.1, 1e-5,
+                                             residual=cl(rs[i * N:(i + 1) * N]) if with_res else None, relu=relu)
+                           for i in range(G)], 0)
+        y.backward(dy)
+        return y.detach(), xs.grad, ws.grad, bs.grad, (rs.grad if with_res else None), rm, rv
+
+    a, bsep = run(G), run(1)
+    assert torch.equal(a[0], bsep[0]) and torch.equal(a[1], bsep[1])          # same kernels, same row ranges
+    assert torch.allclose(a[2], bsep[2], rtol=1e-5, atol=1e-4) and torch.allclose(a[3], bsep[3], rtol=1e-5, atol=1e-4)
+    if with_res:
+        assert torch.equal(a[4], bsep[4])
+    assert torch.allclose(a[5], bsep[5], rtol=1e-6, atol=1e-7) and torch.allclose(a[6], bsep[6], rtol=1e-6, atol=1e-7)

@@ -35,12 +35,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const T* __rest
                                                                  const float* __restrict__ beta,
                                                                  long long M, int C, int rows_per_split, int relu,
                                                                  float* __restrict__ ws) {
+  // M = rows of ONE statistics group; blockIdx.z = group (consecutive row ranges of the tensor)
   __shared__ float lds[2][BN_RY][64 + 1];
   const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
-  const int cg = blockIdx.x, s = blockIdx.y;
-  const long long r0 = (long long)s * rows_per_split;
-  const long long r1 = (r0 + rows_per_split < M) ? r0 + rows_per_split : M;
+  const int cg = blockIdx.x, s = blockIdx.y, grp = blockIdx.z;
+  const long long base = (long long)grp * M;
+  const long long r0 = base + (long long)s * rows_per_split;
+  const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)cg * 64 + (size_t)cx * 8;
+  ws += (size_t)grp * gridDim.y * C * 2;
+  if (MODE == 1) { mean += (size_t)grp * C; invstd += (size_t)grp * C; }
   float a[8], b[8], mu[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[i] = 0.f; b[i] = 0.f; mu[i] = 0.f; sc[i] = 0.f; sh[i] = 0.f; }
@@ -125,23 +129,27 @@ __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, in
 }
 
 __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_fwd_kernel(const float* __restrict__ ws, int S, int C, long long M,
-                                                                    float eps, float momentum,
-                                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  float A, B;
-  bn_sum_partials(ws, S, C, blockIdx.x, A, B);
-  if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const double m = (double)A / (double)M;
-    double var = (double)B / (double)M - m * m;      // biased variance, formed in double
-    var = var > 0.0 ? var : 0.0;
-    save_mean[c] = (float)m;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-      const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+                                                                        int G, float eps, float momentum,
+                                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                        float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  // groups in order: the running statistics receive one momentum update per group, exactly like G separate calls
+  for (int grp = 0; grp < G; ++grp) {
+    float A, B;
+    bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
+    if (threadIdx.x < 64) {
+      const int c = blockIdx.x * 64 + threadIdx.x;
+      const double m = (double)A / (double)M;
+      double var = (double)B / (double)M - m * m;      // biased variance, formed in double
+      var = var > 0.0 ? var : 0.0;
+      save_mean[(size_t)grp * C + c] = (float)m;
+      save_invstd[(size_t)grp * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
     }
+    __syncthreads();      // bn_sum_partials' LDS is reused by the next group
   }
 }
 
@@ -151,9 +159,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               long long M, int C, int rows_per_split, int relu, T* __restrict__ y) {
   const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
-  const long long r0 = (long long)blockIdx.y * rows_per_split;
-  const long long r1 = (r0 + rows_per_split < M) ? r0 + rows_per_split : M;
+  const int grp = blockIdx.z;
+  const long long base = (long long)grp * M;
+  const long long r0 = base + (long long)blockIdx.y * rows_per_split;
+  const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
+  mean += (size_t)grp * C;
+  invstd += (size_t)grp * C;
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -186,25 +198,36 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
   }
 }
 
-// dgamma, dbeta and the dx coefficients  dx = k0 * g + k1 * x + k2
+// dgamma, dbeta (summed over the statistics groups) and per group the dx coefficients  dx = k0 * g + k1 * x + k2
 __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_bwd_kernel(const float* __restrict__ ws, int S, int C, long long M,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                    const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                                    float* __restrict__ dbeta, float* __restrict__ coef) {
-  float A, B;
-  bn_sum_partials(ws, S, C, blockIdx.x, A, B);
+                                                                        int G, const float* __restrict__ gamma,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                        float* __restrict__ coef) {
+  float dg_tot = 0.f, db_tot = 0.f;
+  for (int grp = 0; grp < G; ++grp) {
+    float A, B;
+    bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
+    if (threadIdx.x < 64) {
+      const int c = blockIdx.x * 64 + threadIdx.x;
+      const float is = invstd[(size_t)grp * C + c], mu = mean[(size_t)grp * C + c];
+      const float dg = B * is;                     // sum g * xhat
+      dg_tot += dg;
+      db_tot += A;
+      const float k0 = gamma[c] * is;
+      const float inv_m = 1.f / (float)M;
+      const float k1 = -k0 * is * dg * inv_m;      // multiplies (x - mean)
+      float* co = coef + ((size_t)grp * C + c) * 3;
+      co[0] = k0;
+      co[1] = k1;
+      co[2] = -k0 * A * inv_m - k1 * mu;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x < 64) {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    const float is = invstd[c], mu = mean[c];
-    const float dg = B * is;                     // sum g * xhat
-    dgamma[c] = dg;
-    dbeta[c] = A;
-    const float k0 = gamma[c] * is;
-    const float inv_m = 1.f / (float)M;
-    const float k1 = -k0 * is * dg * inv_m;      // multiplies (x - mean)
-    coef[(size_t)c * 3 + 0] = k0;
-    coef[(size_t)c * 3 + 1] = k1;
-    coef[(size_t)c * 3 + 2] = -k0 * A * inv_m - k1 * mu;
+    dgamma[c] = dg_tot;
+    dbeta[c] = db_tot;
   }
 }
 
@@ -215,9 +238,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, long long M, int C, int rows_per_split,
                                                            int relu, T* __restrict__ dx, T* __restrict__ dres) {
   const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
-  const long long r0 = (long long)blockIdx.y * rows_per_split;
-  const long long r1 = (r0 + rows_per_split < M) ? r0 + rows_per_split : M;
+  const int grp = blockIdx.z;
+  const long long base = (long long)grp * M;
+  const long long r0 = base + (long long)blockIdx.y * rows_per_split;
+  const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
+  coef += (size_t)grp * C * 3;
+  mean += (size_t)grp * C;
+  invstd += (size_t)grp * C;
   float k0[8], k1[8], k2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -282,73 +310,77 @@ static inline int bn_rows_per_split(long long M, int S) {
 
 template <typename T>
 static int run_bn_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* rmean, float* rvar,
-                      float momentum, float eps, int relu, long long M, int C, void* y, float* save_mean, float* save_invstd,
+                      float momentum, float eps, int relu, long long M, int G, int C, void* y, float* save_mean, float* save_invstd,
                       float* ws, hipStream_t st) {
-  const int S = bn_splits(M, C, 1024, 512), rps = bn_rows_per_split(M, S);
-  const int S_eff = (int)((M + rps - 1) / rps);
-  hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
-                     (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, rps, 0, ws);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, M, eps, momentum,
+  const long long Mg = M / G;                      // rows per statistics group
+  const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S_eff = (int)((Mg + rps - 1) / rps);
+  hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
+                     (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C, rps, 0, ws);
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, eps, momentum,
                      rmean, rvar, save_mean, save_invstd);
-  const int S2 = bn_splits(M, C, 2048, 4096), rps2 = bn_rows_per_split(M, S2);
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((M + rps2 - 1) / rps2)), dim3(BN_THREADS), 0, st, (const T*)x,
-                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, M, C, rps2, relu, (T*)y);
+  const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)x,
+                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
 template <typename T>
 static int run_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean, const float* invstd,
-                      int relu, long long M, int C, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
-  const int S = bn_splits(M, C, 1024, 512), rps = bn_rows_per_split(M, S);
-  const int S_eff = (int)((M + rps - 1) / rps);
-  float* coef = ws + (size_t)2 * S_eff * C;
-  hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
-                     (const T*)y, mean, invstd, gamma, beta, M, C, rps, relu, ws);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, M, gamma, mean,
+                      int relu, long long M, int G, int C, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
+  const long long Mg = M / G;
+  const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S_eff = (int)((Mg + rps - 1) / rps);
+  float* coef = ws + (size_t)2 * S_eff * C * G;
+  hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
+                     (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, gamma, mean,
                      invstd, dgamma, dbeta, coef);
-  const int S2 = bn_splits(M, C, 2048, 4096), rps2 = bn_rows_per_split(M, S2);
-  hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((M + rps2 - 1) / rps2)), dim3(BN_THREADS), 0, st, (const T*)dy,
-                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, M, C, rps2, relu, (T*)dx, (T*)dres);
+  const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)dy,
+                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
 }  // namespace td
 
-extern "C" long long td_bn_workspace_floats(long long M, int C) {
-  if (M <= 0 || C <= 0 || C % 64 != 0) return 0;
-  const int S = td::bn_splits(M, C, 1024, 512);
-  return (long long)2 * S * C + (long long)3 * C;
+static bool bn_shape_ok(long long M, int G, int C) { return G >= 1 && G <= 64 && M > 0 && C > 0 && M % G == 0; }
+
+extern "C" long long td_bn_workspace_floats(long long M, int groups, int C) {
+  if (!bn_shape_ok(M, groups, C) || C % 64 != 0) return 0;
+  const int S = td::bn_splits(M / groups, C, 1024 / groups, 512);
+  return ((long long)2 * S * C + (long long)3 * C) * groups;
 }
 
 extern "C" int td_bn_fwd(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float momentum, float eps, int relu, long long M, int C,
-                         void* y, float* save_mean, float* save_invstd, float* workspace, td_stream_t stream) {
-  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0) return TD_ERR_BAD_ARG;
+                         float* running_mean, float* running_var, float momentum, float eps, int relu, long long M, int groups,
+                         int C, void* y, float* save_mean, float* save_invstd, float* workspace, td_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || !bn_shape_ok(M, groups, C)) return TD_ERR_BAD_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return TD_ERR_BAD_ARG;
   if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
   if (dtype == TD_DTYPE_BF16)
-    return td::run_bn_fwd<__hip_bfloat16>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, M, C, y,
+    return td::run_bn_fwd<__hip_bfloat16>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, M, groups, C, y,
                                           save_mean, save_invstd, workspace, (hipStream_t)stream);
   if (dtype == TD_DTYPE_F32)
-    return td::run_bn_fwd<float>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, M, C, y, save_mean,
+    return td::run_bn_fwd<float>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, M, groups, C, y, save_mean,
                                  save_invstd, workspace, (hipStream_t)stream);
   return TD_ERR_UNSUPPORTED;
 }
 
 extern "C" int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta, const float* save_mean,
-                         const float* save_invstd, int relu, long long M, int C, void* dx, void* dresidual, float* dgamma,
-                         float* dbeta, float* workspace, td_stream_t stream) {
-  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0)
+                         const float* save_invstd, int relu, long long M, int groups, int C, void* dx, void* dresidual,
+                         float* dgamma, float* dbeta, float* workspace, td_stream_t stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || !bn_shape_ok(M, groups, C))
     return TD_ERR_BAD_ARG;
   if (relu < 0 || relu > 1) return TD_ERR_BAD_ARG;
   if (relu && !y && (!beta || dresidual)) return TD_ERR_BAD_ARG;   // the mask comes from y, or is recomputed from x (no residual)
   if (relu && !y) relu = 2;
   if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
   if (dtype == TD_DTYPE_BF16)
-    return td::run_bn_bwd<__hip_bfloat16>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, C, dx, dresidual, dgamma, dbeta,
+    return td::run_bn_bwd<__hip_bfloat16>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, dx, dresidual, dgamma, dbeta,
                                           workspace, (hipStream_t)stream);
   if (dtype == TD_DTYPE_F32)
-    return td::run_bn_bwd<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, C, dx, dresidual, dgamma, dbeta, workspace,
+    return td::run_bn_bwd<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, dx, dresidual, dgamma, dbeta, workspace,
                                  (hipStream_t)stream);
   return TD_ERR_UNSUPPORTED;
 }

@@ -8,7 +8,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import MONO
-from ..networks import DepthEncoder, DepthDecoder, PoseEncoder, PoseDecoder, Encoder, Decoder, install_counter_hook
+from ..networks import (DepthEncoder, DepthDecoder, PoseEncoder, PoseDecoder, Encoder, Decoder, install_counter_hook,
+                        bn_groups, bn_groups_supported)
 from .layers import SSIM, Backproject, Project
 from .. import hotpath
 
@@ -223,14 +224,31 @@ class mono_fm_joint(nn.Module):
         outputs = {}
         if pose_feats is None:
             pose_feats = {f: resize_bilinear(inputs["color_aug", f, 0], [192, 640]) for f in self.opt.frame_ids}
-        for f in self.opt.frame_ids[1:]:
-            if f == "s":
-                continue
-            pair = [pose_feats[f], pose_feats[0]] if f < 0 else [pose_feats[0], pose_feats[f]]
-            axisangle, translation = self.PoseDecoder(self.PoseEncoder(torch.cat(pair, 1)))
+        frames = [f for f in self.opt.frame_ids[1:] if f != "s"]
+        pairs = [torch.cat([pose_feats[f], pose_feats[0]] if f < 0 else [pose_feats[0], pose_feats[f]], 1)
+                 for f in frames]
+        if self._batch_frames(pairs):
+            # one pass over the stacked pairs; BatchNorm keeps one set of batch statistics per pair
+            # (networks.bn_groups), so this equals the reference's separate passes (net.py:172-178)
+            with bn_groups(len(pairs)):
+                axisangle, translation = self.PoseDecoder(self.PoseEncoder(torch.cat(pairs, 0)))
+            n = pairs[0].shape[0]
+            per_pair = [(axisangle[i * n:(i + 1) * n], translation[i * n:(i + 1) * n]) for i in range(len(pairs))]
+        else:
+            per_pair = [self.PoseDecoder(self.PoseEncoder(x)) for x in pairs]
+        for f, (axisangle, translation) in zip(frames, per_pair):
             outputs[("cam_T_cam", 0, f)] = self.transformation_from_parameters(
                 axisangle[:, 0], translation[:, 0], invert=(f < 0))
         return outputs
+
+    def _batch_frames(self, tensors):
+        """Stack same-network passes over different frames into one batch: only where the grouped BatchNorm
+        kernels run (HIP, training) so that batch statistics stay per pass."""
+        if not (len(tensors) > 1 and self.training and tensors[0].is_cuda and self.opt.get("batch_frame_passes", True)):
+            return False
+        if getattr(self, "_bn_groups_ok", None) is None:
+            self._bn_groups_ok = bn_groups_supported(self)
+        return self._bn_groups_ok
 
     def transformation_from_parameters(self, axisangle, translation, invert=False):
         """net.py:225-236: M = R^T Trans(-t) when inverting, else Trans(t) R."""

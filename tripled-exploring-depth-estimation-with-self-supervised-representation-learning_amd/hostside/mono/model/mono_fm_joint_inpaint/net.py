@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from ..registry import MONO
 from ..mono_fm_joint.net import mono_fm_joint, resize_bilinear
-from ..networks import ColorDecoder, Conv1x1, DepthDecoder, Encoder, IdentityPartial
+from ..networks import ColorDecoder, Conv1x1, DepthDecoder, Encoder, IdentityPartial, bn_groups
 from .color_conversions import rgb2lab
 
 
@@ -56,7 +56,15 @@ class mono_fm_joint_inpaint(mono_fm_joint):
         if not tgt_f.is_cuda or opt.get("keep_warped_images", False) or "s" in opt.frame_ids:
             return None
         from tripled_amd import ops
-        src_f = [self._source_features(inputs[("color", f, 0)]) for f in opt.frame_ids[1:]]
+        imgs = [inputs[("color", f, 0)] for f in opt.frame_ids[1:]]
+        if self._batch_frames(imgs):
+            # both source frames through the extractor in one stacked pass (per-pass BatchNorm statistics)
+            with bn_groups(len(imgs)):
+                stacked = self._source_features(torch.cat(imgs, 0))
+            n = imgs[0].shape[0]
+            src_f = [stacked[i * n:(i + 1) * n] for i in range(len(imgs))]
+        else:
+            src_f = [self._source_features(img) for img in imgs]
         if not ops.featwarp_supported(tgt_f, src_f):
             return None
         K = inputs["K"].float().clone()

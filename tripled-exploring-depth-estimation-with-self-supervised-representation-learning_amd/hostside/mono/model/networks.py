@@ -47,10 +47,14 @@ class BatchNorm(nn.BatchNorm2d):
 
     def forward(self, x):
         if self.training and self.track_running_stats and self.momentum is not None:
-            self._pending += 1
+            g = _BN_GROUPS[0]
+            self._pending += g
             if self._hip_ok(x):
                 return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                         self.momentum, self.eps)
+                                            self.momentum, self.eps, groups=g)
+            if g > 1:      # stacked passes without the HIP kernels: one ATen call per pass, in order
+                return torch.cat([F.batch_norm(c, self.running_mean, self.running_var, self.weight, self.bias, True,
+                                               self.momentum, self.eps) for c in x.chunk(g, 0)], 0)
             return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
                                 self.momentum, self.eps)
         return super().forward(x)
@@ -58,10 +62,38 @@ class BatchNorm(nn.BatchNorm2d):
     def fused(self, x, residual=None, relu=True):
         """bn(x) [+ residual] [-> relu] -- one HIP apply pass on channels_last CUDA activations in training."""
         if self._hip_ok(x):
-            self._pending += 1
+            g = _BN_GROUPS[0]
+            self._pending += g
             return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                     self.momentum, self.eps, residual=residual, relu=relu)
+                                        self.momentum, self.eps, residual=residual, relu=relu, groups=g)
         return _plain_bn_act(self, x, residual, relu)
+
+
+_BN_GROUPS = [1]
+
+
+class bn_groups:
+    """``with bn_groups(G): net(torch.cat(passes, 0))`` -- every BatchNorm inside treats the batch as G stacked
+    passes with separate batch statistics (and G running-statistics updates, G counter increments), so one
+    launch sequence over the stacked batch equals the reference's G separate forward passes of that network
+    (mono_fm_joint/net.py:172-178 pose pairs, :221 source-frame features)."""
+
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        self.prev = _BN_GROUPS[0]
+        _BN_GROUPS[0] = self.groups
+
+    def __exit__(self, *exc):
+        _BN_GROUPS[0] = self.prev
+        return False
+
+
+def bn_groups_supported(model):
+    """Stacked passes need every normalisation layer to be this module's BatchNorm (not SyncBatchNorm etc.)."""
+    return not any(isinstance(m, nn.modules.batchnorm._BatchNorm) and not isinstance(m, BatchNorm)
+                   for m in model.modules())
 
 
 def _plain_bn_act(bn, x, residual, relu):

@@ -39,9 +39,9 @@ SIGNATURES = {
     "td_maxpool5_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "td_join_fwd": (_I, [_P, _P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P]),
     "td_join_bwd": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P]),
-    "td_bn_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I]),
-    "td_bn_fwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _P, _P, _P, _P, _P]),
-    "td_bn_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _P, _P, _P, _P, _P, _P]),
+    "td_bn_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _I]),
+    "td_bn_fwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P]),
+    "td_bn_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _P]),
     "td_edge_weights": (_I, [_P, _I, _I, _I, _F, ctypes.POINTER(ctypes.c_float), _P, _P]),
     "td_featreg_num_blocks": (_I, [_I, _I, _I, _I]),
     "td_featreg_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),

@@ -257,23 +257,23 @@ class _BatchNormAct(torch.autograd.Function):
     """F.batch_norm(training=True) [+ residual] [-> relu] on a channels_last tensor, three launches each way."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups):
         lib = native.load()
         N, C, H, W = x.shape
         M = N * H * W
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        mean = torch.empty(C, device=x.device, dtype=torch.float32)
-        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = torch.empty(lib.td_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        mean = torch.empty(groups * C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(groups * C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.td_bn_workspace_floats(M, groups, C), device=x.device, dtype=torch.float32)
         native.check(lib.td_bn_fwd(_raw(x), _raw(residual) if residual is not None else None, native.DTYPE_CODES[x.dtype],
                                    native.ptr(weight), native.ptr(bias),
                                    native.ptr(running_mean) if running_mean is not None else None,
                                    native.ptr(running_var) if running_var is not None else None,
-                                   float(momentum), float(eps), int(relu), M, C, _raw(y), native.ptr(mean),
+                                   float(momentum), float(eps), int(relu), M, groups, C, _raw(y), native.ptr(mean),
                                    native.ptr(invstd), native.ptr(ws), native.stream()), "td_bn_fwd")
         # the ReLU mask is re-derived from x in backward unless a residual went into the pre-activation
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, mean, invstd)
-        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.relu, ctx.has_res, ctx.groups = bool(relu), residual is not None, groups
         return y
 
     @staticmethod
@@ -289,14 +289,14 @@ class _BatchNormAct(torch.autograd.Function):
         dres = torch.empty_like(x, memory_format=torch.channels_last) if (ctx.has_res and ctx.relu) else None
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = torch.empty(lib.td_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.td_bn_workspace_floats(M, ctx.groups, C), device=x.device, dtype=torch.float32)
         native.check(lib.td_bn_bwd(_raw(dy), _raw(x), _raw(y) if y is not None else None, native.DTYPE_CODES[x.dtype],
-                                   native.ptr(weight), native.ptr(bias), native.ptr(mean), native.ptr(invstd), int(ctx.relu), M, C,
+                                   native.ptr(weight), native.ptr(bias), native.ptr(mean), native.ptr(invstd), int(ctx.relu), M, ctx.groups, C,
                                    _raw(dx), _raw(dres) if dres is not None else None, native.ptr(dgamma),
                                    native.ptr(dbeta), native.ptr(ws), native.stream()), "td_bn_bwd")
         if ctx.has_res and not ctx.relu:
             dres = dy
-        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None, None
 
 
 def batchnorm_act_supported(x, weight):
@@ -305,14 +305,17 @@ def batchnorm_act_supported(x, weight):
             and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def batchnorm_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False):
-    """Training-mode BatchNorm2d + optional residual add + optional ReLU (reference: resnet.py:30-49, 66-86)."""
+def batchnorm_act(x, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False, groups=1):
+    """Training-mode BatchNorm2d + optional residual add + optional ReLU (reference: resnet.py:30-49, 66-86).
+    ``groups`` > 1: the batch is that many stacked passes, each normalised with its own batch statistics."""
+    if x.shape[0] % groups:
+        raise ValueError("batch %d is not %d stacked passes" % (x.shape[0], groups))
     if not batchnorm_act_supported(x, weight):
         raise native.NativeLibraryError("batchnorm_act needs a channels_last f32/bf16 HIP tensor with C % 64 == 0")
     if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
-    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
+    return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups)
 
 
 def edge_weights(img_at_scale, a, scale6):
