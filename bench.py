@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-graph", action="store_true", help="do not capture the step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--prune-extractor-tail", action="store_true",
+                   help="skip the ResNet tails whose output the reference discards (net.py:221); NOT the headline configuration")
     p.add_argument("--h2d", action="store_true", help="include the host-to-device copy of every batch in the timed step")
     p.add_argument("--split-timing", action="store_true", help="two graphs (fwd+bwd | clip+Adam) and report each")
     p.add_argument("--flat", action="store_true", help="flat bf16/fp32 parameter store (tripled_amd/flat_amp.py) instead of autocast + per-parameter Adam")
@@ -313,6 +315,8 @@ def main():
     torch.backends.cudnn.benchmark = {"config": bool(cfg.get("cudnn_benchmark", False)), "on": True,
                                       "off": False}[args.miopen_find]
     m = cfg.model
+    if args.prune_extractor_tail:
+        m["prune_extractor_tail"] = True
     B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
     torch.manual_seed(1024)
     model = build_model(cfg, dev, channels_last=True)
@@ -442,7 +446,8 @@ def main():
                 "syncbn": bool(use_syncbn and world > 1),
                 "grad_sync": ("none" if world == 1 else ("bucketed RCCL all-reduce between two HIP graphs" if graphed
                               else "bucketed RCCL all-reduce overlapped with backward")),
-                "h2d_in_step": bool(args.h2d), "final_loss": round(final_loss, 6)},
+                "h2d_in_step": bool(args.h2d), "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
+                "final_loss": round(final_loss, 6)},
         }
         if not args.no_roofline:
             kern = roofline_of_hot_kernels(cfg, batch)
