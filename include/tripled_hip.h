@@ -268,6 +268,16 @@ int td_reflpad1_bwd(const void* grad_out, int dtype, int N, int H, int W, int C,
                     td_stream_t stream);
 
 /*
+ * out = ReflectionPad2d(1)(F.interpolate(in, scale_factor=2, mode="nearest")) without materialising the
+ * up-sampled tensor: the `iconv(upsample(upconv(x)))` step of the image decoders
+ * (mono/model/mono_fm_joint/decoder.py:40-57).  in [N,H,W,C], out [N,2H+2,2W+2,C], channels-last, C % 8 == 0.
+ * td_up2_reflpad1_bwd is the exact adjoint (gather form, <= 16 taps at a corner, 4 in the interior).
+ */
+int td_up2_reflpad1_fwd(const void* in, int dtype, int N, int H, int W, int C, void* out, td_stream_t stream);
+int td_up2_reflpad1_bwd(const void* grad_out, int dtype, int N, int H, int W, int C, void* grad_in,
+                        td_stream_t stream);
+
+/*
  * Feature-metric term: generate_features_pred (mono/model/mono_fm_joint/net.py:196-223) +
  * compute_perceptional_loss (:63-65) + min over source frames (mono_fm_joint_inpaint/net.py:58-70), fused.
  *   tgt, src[i]  [B,h,w,C] channels-last feature maps (C % 64 == 0; dtype f32 or bf16); n_src <= 2

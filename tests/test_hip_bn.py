@@ -125,3 +125,19 @@ def test_grouped_batchnorm_equals_separate_passes(relu, with_res, dtype):
     if with_res:
         assert torch.equal(a[4], bsep[4])
     assert torch.allclose(a[5], bsep[5], rtol=1e-6, atol=1e-7) and torch.allclose(a[6], bsep[6], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 5, 7), (1, 8, 1, 1), (3, 64, 12, 20), (1, 8, 2, 1)])
+def test_up2_reflpad1_matches_aten(shape, dtype):
+    """ReflectionPad2d(1)(upsample x2 nearest), forward and adjoint (decoder.py:40-57)."""
+    x = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = ops.up2_reflpad1(x)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.pad(F.interpolate(xr, scale_factor=2, mode="nearest"), (1, 1, 1, 1), mode="reflect")
+    assert out.shape == ref.shape and torch.equal(out.float(), ref)
+    g = torch.randn_like(ref).to(dtype).contiguous(memory_format=torch.channels_last)
+    out.backward(g)
+    ref.backward(g.float())
+    tol = 1e-5 if dtype == torch.float32 else 4e-2        # up to 16 bf16 gradients summed in fp32, rounded once
+    assert torch.allclose(x.grad.float(), xr.grad, rtol=tol, atol=tol)

@@ -436,6 +436,16 @@ class Conv3x3(nn.Module):
         return y[:, :cout] if cout_p != cout else y
 
 
+    def forward_up(self, x):
+        """self(upsample(x)): x2 nearest + reflection pad in one HIP pass when the layout allows it."""
+        cin = self.conv.weight.shape[1]
+        if (self.use_refl and x.is_cuda and x.shape[1] == cin and cin % 8 == 0 and self.conv.weight.shape[0] % 8 == 0
+                and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous(memory_format=torch.channels_last)
+                and not os.environ.get("TD_NO_FUSED_UPSAMPLE")):
+            return self.conv(_ops().up2_reflpad1(x))
+        return self.forward(upsample(x))
+
+
 class Conv5x5(nn.Module):
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
@@ -454,6 +464,10 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         return self.nonlin(self.conv(x))
+
+    def forward_up(self, x):
+        """self(upsample(x)) without materialising the up-sampled tensor (Conv3x3.forward_up)."""
+        return self.nonlin(self.conv.forward_up(x))
 
 
 class CRPBlock(nn.Module):
@@ -595,11 +609,11 @@ class Decoder(nn.Module):
         return outputs
 
     def forward(self, input_features, frame_id=0):
-        x = self.iconv5(upsample(self.upconv5(input_features[4])))
-        i4 = self.iconv4(upsample(self.upconv4(x)))
-        i3 = self.iconv3(upsample(self.upconv3(i4)))
-        i2 = self.iconv2(upsample(self.upconv2(i3)))
-        i1 = self.iconv1(upsample(self.upconv1(i2)))
+        x = self.iconv5.forward_up(self.upconv5(input_features[4]))      # iconv(upsample(upconv(.)))
+        i4 = self.iconv4.forward_up(self.upconv4(x))
+        i3 = self.iconv3.forward_up(self.upconv3(i4))
+        i2 = self.iconv2.forward_up(self.upconv2(i3))
+        i1 = self.iconv1.forward_up(self.upconv1(i2))
         self.outputs = self._heads({}, "res_img", frame_id, i4, i3, i2, i1)
         return self.outputs
 
@@ -621,29 +635,32 @@ class ColorDecoder(Decoder):
         e1, e2, e3, e4, e5 = input_features
         m = self.skip_connection_multiplier
 
-        def with_disp(x, scale):
-            dsp = F.interpolate(outputs[("disp", frame_id, scale)], list(x.shape[2:]), mode="bilinear",
+        def with_disp(low, scale):
+            # disparity resized to the up-sampled resolution of ``low``
+            dsp = F.interpolate(outputs[("disp", frame_id, scale)], [2 * low.shape[2], 2 * low.shape[3]], mode="bilinear",
                                 align_corners=False)
-            return (dsp * m).to(x.dtype)     # keep the decoder trunk in the activation dtype under autocast
+            return (dsp * m).to(low.dtype)     # keep the decoder trunk in the activation dtype under autocast
 
-        u5 = upsample(self.upconv5(e5))
-        i5 = self.iconv5(u5) + with_disp(u5, 3)
-        u4 = upsample(self.upconv4(i5))
+        # nearest up-sampling commutes with the skip additions (upsample(a) + upsample(b) == upsample(a + b), also
+        # after bf16 rounding), so they are taken at the low resolution and the up-sampling is fused into the pad
+        l5 = self.upconv5(e5)
+        i5 = self.iconv5.forward_up(l5) + with_disp(l5, 3)
+        l4 = self.upconv4(i5)
         if skip_layers[0]:
-            u4 = u4 + upsample(self.upconv5_skip(e4))
-        i4 = self.iconv4(u4) + with_disp(u4, 2)
-        u3 = upsample(self.upconv3(i4))
+            l4 = l4 + self.upconv5_skip(e4)
+        i4 = self.iconv4.forward_up(l4) + with_disp(l4, 2)
+        l3 = self.upconv3(i4)
         if skip_layers[1]:
-            u3 = u3 + upsample(self.upconv4_skip(e3))
-        i3 = self.iconv3(u3) + with_disp(u3, 1)
-        u2 = upsample(self.upconv2(i3))
+            l3 = l3 + self.upconv4_skip(e3)
+        i3 = self.iconv3.forward_up(l3) + with_disp(l3, 1)
+        l2 = self.upconv2(i3)
         if skip_layers[2]:
-            u2 = u2 + upsample(self.upconv3_skip(e2))
-        i2 = self.iconv2(u2) + with_disp(u2, 0)
-        u1 = upsample(self.upconv1(i2))
+            l2 = l2 + self.upconv3_skip(e2)
+        i2 = self.iconv2.forward_up(l2) + with_disp(l2, 0)
+        l1 = self.upconv1(i2)
         if skip_layers[3]:
-            u1 = u1 + upsample(self.upconv2_skip(e1))
-        i1 = self.iconv1(u1)
+            l1 = l1 + self.upconv2_skip(e1)
+        i1 = self.iconv1.forward_up(l1)
         return self._heads(outputs, "auto_res_img", frame_id, i4, i3, i2, i1)
 
 

@@ -51,6 +51,8 @@ SIGNATURES = {
     "td_recon_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     "td_reflpad1_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "td_reflpad1_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "td_up2_reflpad1_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "td_up2_reflpad1_bwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "td_featwarp_num_blocks": (_I, [_I, _I, _I]),
     "td_featwarp_fwd": (_I, [_P, _PTRARR, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "td_featwarp_bwd": (_I, [_P, _PTRARR, _I, _I, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _P, _PTRARR,

@@ -433,6 +433,42 @@ class _ReflPad1(torch.autograd.Function):
         return gin
 
 
+class _Up2ReflPad1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = native.load()
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, 2 * H + 2, 2 * W + 2), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_up2_reflpad1_fwd(_raw(x), native.DTYPE_CODES[x.dtype], N, H, W, C, _raw(out),
+                                             native.stream()), "td_up2_reflpad1_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        N, C, Ho, Wo = g.shape
+        H, W = (Ho - 2) // 2, (Wo - 2) // 2
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty((N, C, H, W), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_up2_reflpad1_bwd(_raw(g), native.DTYPE_CODES[g.dtype], N, H, W, C, _raw(gin),
+                                             native.stream()), "td_up2_reflpad1_bwd")
+        return gin
+
+
+def up2_reflpad1_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def up2_reflpad1(x):
+    """ReflectionPad2d(1)(interpolate(x, scale_factor=2, mode="nearest")) on a channels_last HIP tensor
+    (reference: decoder.py:40-57)."""
+    if not up2_reflpad1_supported(x):
+        raise native.NativeLibraryError("up2_reflpad1 needs a channels_last f32/bf16 HIP tensor with C % 8 == 0")
+    return _Up2ReflPad1.apply(x)
+
+
 def reflpad1_supported(x):
     return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 8 == 0
             and x.shape[2] >= 2 and x.shape[3] >= 2 and x.is_contiguous(memory_format=torch.channels_last))
