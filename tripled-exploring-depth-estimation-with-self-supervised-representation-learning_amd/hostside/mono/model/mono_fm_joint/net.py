@@ -233,7 +233,7 @@ class mono_fm_joint(nn.Module):
             with bn_groups(len(pairs)):
                 axisangle, translation = self.PoseDecoder(self.PoseEncoder(torch.cat(pairs, 0)))
             n = pairs[0].shape[0]
-            per_pair = [(axisangle[i * n:(i + 1) * n], translation[i * n:(i + 1) * n]) for i in range(len(pairs))]
+            per_pair = list(zip(axisangle.split(n, 0), translation.split(n, 0)))
         else:
             per_pair = [self.PoseDecoder(self.PoseEncoder(x)) for x in pairs]
         for f, (axisangle, translation) in zip(frames, per_pair):

@@ -61,8 +61,7 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             # both source frames through the extractor in one stacked pass (per-pass BatchNorm statistics)
             with bn_groups(len(imgs)):
                 stacked = self._source_features(torch.cat(imgs, 0))
-            n = imgs[0].shape[0]
-            src_f = [stacked[i * n:(i + 1) * n] for i in range(len(imgs))]
+            src_f = list(stacked.split(imgs[0].shape[0], 0))      # split: its backward is one cat, not zero-filled slices
         else:
             src_f = [self._source_features(img) for img in imgs]
         if not ops.featwarp_supported(tgt_f, src_f):
