@@ -158,3 +158,44 @@ def test_full_size_properties(ops):
     grid = torch.stack(torch.broadcast_tensors(gx.view(1, 1, W), gy.view(1, H, 1)), -1).repeat(B, 1, 1, 1)
     expect = geometry.grid_sample_border(fr[-1], grid)
     assert float((w[0].cpu() - expect).abs().max()) < 2e-4
+
+
+def _oracle_backward(fr, K, invK, Ts, disp, noise, forced, B, H, W, scale_by=1.0):
+    """Oracle autograd of one photometric scale under a given arg-min -> (d disp, d P)."""
+    srcs = [fr[-1], fr[1]]
+    dr = disp.clone().requires_grad_(True)
+    Pr = _P(K, Ts).requires_grad_(True)
+    warped = []
+    for i in range(2):
+        up = geometry.upsample_bilinear(dr, H, W)
+        _, depth = geometry.disp_to_depth(up, 0.1, 100.0)
+        pts = geometry.backproject(depth, invK)
+        cam = torch.matmul(Pr[i], pts)
+        uv = cam[:, :2] / (cam[:, 2:3] + 1e-7)
+        gx = (uv[:, 0].reshape(B, H, W) / (W - 1) - 0.5) * 2
+        gy = (uv[:, 1].reshape(B, H, W) / (H - 1) - 0.5) * 2
+        warped.append(geometry.grid_sample_border(srcs[i], torch.stack([gx, gy], -1)))
+    nz = [noise[0].unsqueeze(1), noise[1].unsqueeze(1)]
+    vals, _, _ = photometric.min_reprojection(fr[0], srcs, warped, nz, True, forced_index=forced)
+    loss = vals.mean() / 4 * scale_by
+    loss.backward()
+    return float(loss), dr.grad, Pr.grad
+
+
+def test_full_size_backward_matches_oracle(ops):
+    """BASELINE size (B=12, 192x640, scale 1): the shape at which the wave tasks are 13/14 rows tall with a
+    ragged last chunk (td_common.h::pick_rows) -- gradients w.r.t. the disparity and the projection matrices
+    against the oracle's autograd, under the kernel's own arg-min (as in test_backward_matches_oracle_autograd)."""
+    B, H, W, hs, ws = 12, 192, 640, 48, 160
+    fr, K, invK, Ts, disp, noise = _case(11, B, H, W, hs, ws)
+    tgt = fr[0].cuda()
+    srcs = [fr[-1].cuda(), fr[1].cuda()]
+    idl = ops.photo_identity(tgt, srcs)
+    d = disp.cuda().requires_grad_(True)
+    P = _P(K, Ts).cuda().requires_grad_(True)
+    loss, amin, _ = ops.photometric_scale_loss(d, P, tgt, srcs, invK.cuda(), idl, noise.cuda(), 0.1, 100.0, 4)
+    loss.backward()
+    ref_loss, d_ref, P_ref = _oracle_backward(fr, K, invK, Ts, disp, noise, amin.cpu().long(), B, H, W)
+    assert abs(float(loss) - ref_loss) < 2e-6
+    assert rel_err(d.grad, d_ref) < 2e-3
+    assert rel_err(P.grad, P_ref) < 2e-3
