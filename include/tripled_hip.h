@@ -187,6 +187,16 @@ int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, 
                     void* grad_in, td_stream_t stream);
 
 /*
+ * The ResNet stem pool, nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (mono/model/mono_fm_joint/resnet.py:101),
+ * same conventions as td_maxpool5_*: in [N,H,W,C] -> out / idx [N,Ho,Wo,C] with Ho = (H - 1) / 2 + 1,
+ * idx = dy*3+dx of the selected element; H, W in td_maxpool3s2_bwd are the INPUT sizes.
+ */
+int td_maxpool3s2_fwd(const void* in, int dtype, int N, int H, int W, int C, void* out, uint8_t* idx,
+                      td_stream_t stream);
+int td_maxpool3s2_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, int H, int W, int C,
+                      void* grad_in, td_stream_t stream);
+
+/*
  * Channel concatenation of the DepthDecoder stages on channels-last activations
  * (mono/model/mono_fm_joint/depth_decoder.py:89-103, torch.cat((reduce(l), x, disp), 1)):
  *   out[pix, :] = [a[pix, :C0], b[pix, :C1], tail[pix, :C2], 0 ... 0]   with C0 + C1 + 8 output channels,

@@ -24,3 +24,23 @@ def test_maxpool5_matches_aten(dtype, N, C, H, W):
     yr.backward(go)
     tol = 1e-5 if dtype == torch.float32 else 3e-2   # f32: summation order; bf16: f32 accumulation here, one rounding
     assert float((x.grad.float() - xr.grad.float()).abs().max()) <= tol * max(1.0, float(xr.grad.float().abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (1, 64, 12, 40), (3, 8, 1, 5), (2, 64, 96, 320), (1, 8, 2, 2)])
+def test_maxpool3s2_matches_aten(dtype, N, C, H, W):
+    """ResNet stem pool MaxPool2d(3, 2, 1) (reference resnet.py:101): odd and even sizes, ties."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randint(0, 6, (N, C, H, W), generator=g).float() * 0.25).to(dtype)
+    x = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = ops.maxpool3s2(x)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert y.shape == yr.shape and torch.equal(y, yr)
+    go = torch.randn(yr.shape, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    yr.backward(go)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    assert float((x.grad.float() - xr.grad.float()).abs().max()) <= tol * max(1.0, float(xr.grad.float().abs().max()))

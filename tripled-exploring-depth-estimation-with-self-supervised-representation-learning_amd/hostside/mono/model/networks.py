@@ -218,17 +218,24 @@ class ResNet(nn.Module):
     def stem(self, x):
         return bn_act(self.bn1, self.conv1(x))
 
+    def pool(self, x):
+        """self.maxpool (3x3, stride 2, padding 1): hand-written kernel on channels-last HIP activations."""
+        if x.is_cuda and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
+                and x.is_contiguous(memory_format=torch.channels_last) and not os.environ.get("TD_NO_HIP_STEM_POOL"):
+            return _ops().maxpool3s2(x)
+        return self.maxpool(x)
+
     def pyramid(self, x, extra=None):
         """The five feature maps every encoder here exposes (strides 2, 4, 8, 16, 32);
         ``extra`` optionally adds a conditioning tensor to each level (Encoder.forward)."""
         if extra is None:
             f0 = self.stem(x)
-            f1 = self.layer1(self.maxpool(f0))
+            f1 = self.layer1(self.pool(f0))
             f2 = self.layer2(f1)
             f3 = self.layer3(f2)
             return [f0, f1, f2, f3, self.layer4(f3)]
         f0 = self.stem(x) + extra[0]
-        f1 = self.layer1(self.maxpool(f0)) + extra[1]
+        f1 = self.layer1(self.pool(f0)) + extra[1]
         f2 = self.layer2(f1) + extra[2]
         f3 = self.layer3(f2) + extra[3]
         f4 = self.layer4(f3) + extra[4]
@@ -500,9 +507,22 @@ class CRPBlock(nn.Module):
         return x
 
 
+class ReflPad1(nn.ReflectionPad2d):
+    """nn.ReflectionPad2d(1) that takes the gather-form HIP kernels on channels-last activations."""
+
+    def __init__(self):
+        super().__init__(1)
+
+    def forward(self, x):
+        if x.is_cuda and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] >= 2 and x.shape[3] >= 2:
+            return _ops().reflpad1(x)
+        return super().forward(x)
+
+
 def upshuffle(in_planes, upscale_factor):
     """Sub-pixel x2 up-sampler (reference: layers.py:130-141), ICNR-style initialisation."""
-    block = nn.Sequential(nn.ReflectionPad2d(1),
+    block = nn.Sequential(ReflPad1(),
                           nn.Conv2d(in_planes, in_planes * upscale_factor ** 2, 3, 1, 0),
                           nn.PixelShuffle(upscale_factor), nn.ELU(inplace=True))
     r2 = upscale_factor ** 2

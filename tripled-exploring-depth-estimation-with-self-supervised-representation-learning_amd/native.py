@@ -37,6 +37,8 @@ SIGNATURES = {
     "td_smooth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _P]),
     "td_maxpool5_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_maxpool5_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "td_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "td_maxpool3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "td_join_fwd": (_I, [_P, _P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P]),
     "td_join_bwd": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P]),
     "td_bn_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _I]),

@@ -200,6 +200,41 @@ class _MaxPool5(torch.autograd.Function):
         return gin
 
 
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = native.load()
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        idx = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        native.check(lib.td_maxpool3s2_fwd(_raw(x), native.DTYPE_CODES[x.dtype], N, H, W, C, _raw(out), _raw(idx),
+                                           native.stream()), "td_maxpool3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.in_hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        (idx,) = ctx.saved_tensors
+        N, _, _, C = idx.shape
+        H, W = ctx.in_hw
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        gin = torch.empty((N, C, H, W), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_maxpool3s2_bwd(_raw(g), _raw(idx), native.DTYPE_CODES[g.dtype], N, H, W, C, _raw(gin),
+                                           native.stream()), "td_maxpool3s2_bwd")
+        return gin
+
+
+def maxpool3s2(x):
+    """nn.MaxPool2d(3, 2, 1) on a channels_last CUDA tensor (reference: resnet.py:101)."""
+    if not maxpool5_supported(x):
+        raise native.NativeLibraryError("maxpool3s2 needs a channels_last f32/bf16 HIP tensor with C % 8 == 0")
+    return _MaxPool3s2.apply(x)
+
+
 def maxpool5_supported(x):
     return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 8 == 0
             and x.is_contiguous(memory_format=torch.channels_last))
