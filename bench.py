@@ -95,7 +95,7 @@ class TrainStep:
         on_gpu = batch["K"].is_cuda
         if flat:
             from tripled_amd.flat_amp import FlatMixedPrecision
-            self.flat = FlatMixedPrecision(inner, max_norm=self.max_norm, **ocfg)
+            self.flat = FlatMixedPrecision(inner, max_norm=self.max_norm, lowp=flat == "lowp", **ocfg)
             self.optimizer = self.flat.optimizer
         else:
             # fused multi-tensor Adam on the GPU (same update rule as torch.optim.Adam(lr, weight_decay=0))
@@ -326,8 +326,11 @@ def main():
     use_syncbn = args.syncbn == "on"
     dtype = torch.bfloat16 if args.dtype == "bf16" else None
     split_graph = (world > 1 or args.split_timing) and not use_syncbn and not args.no_graph
-    # flat bf16/fp32 parameter store: opt-in -- measured 2.1 ms/step SLOWER than plain autocast at C2
-    use_flat = dtype is not None and not use_syncbn and args.flat
+    # flat parameter store (tripled_amd/flat_amp.py).  N > 1: fp32 parameters, flat fp32 gradient buffer filled by
+    # batched concatenations after backward -- no wrapper, no per-parameter accumulate kernels, the all-reduce runs
+    # on the flat buffer.  --flat: additionally a bf16 working copy of the conv weights (measured 2.1 ms/step SLOWER
+    # than plain autocast at C2; opt-in).
+    use_flat = dtype is not None and not use_syncbn and (args.flat or (world > 1 and not args.no_graph))
     if world > 1 and not use_flat:
         from mmcv.parallel import MMDistributedDataParallel
         if use_syncbn:
@@ -344,7 +347,7 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]))
-    step = TrainStep(model, cfg, batch, dtype, flat=use_flat)
+    step = TrainStep(model, cfg, batch, dtype, flat=("lowp" if args.flat else "fp32") if use_flat else False)
 
     # warm-up (and capture) on a side stream: autograd's AccumulateGrad nodes then belong to a
     # non-default stream, which whole-step graph capture requires
@@ -444,8 +447,9 @@ def main():
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
                 "parallelism": "dp%d" % world, "hip_graph": graphed,
                 "syncbn": bool(use_syncbn and world > 1),
-                "grad_sync": ("none" if world == 1 else ("bucketed RCCL all-reduce between two HIP graphs" if graphed
-                              else "bucketed RCCL all-reduce overlapped with backward")),
+                "grad_sync": ("none" if world == 1 else ("bucketed RCCL all-reduce of the flat gradient buffer between two HIP graphs"
+                                                          if graphed else ("bucketed RCCL all-reduce after backward" if use_flat
+                                                                           else "bucketed RCCL all-reduce overlapped with backward"))),
                 "h2d_in_step": bool(args.h2d), "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
                 "final_loss": round(final_loss, 6)},
         }

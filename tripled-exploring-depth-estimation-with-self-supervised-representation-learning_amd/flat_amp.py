@@ -13,6 +13,11 @@ contiguous HBM buffers (sized for a 288 GB device, where duplicating the weights
 
 Numerically this is the autocast path: convolutions see bf16(weight) and produce bf16 weight gradients
 in both cases; the master update is the same fp32 Adam.
+
+``lowp=False`` keeps every parameter fp32 (autocast casts per use, as without this class) and only provides
+the flat fp32 gradient/parameter buffers: gradients are gathered by batched concatenations after backward,
+all-reduced in a few large buckets, clipped and stepped by one single-tensor Adam.  That form costs the same as
+the plain step on one GPU and is what ``bench.py --gpus N`` (N > 1) uses between its two HIP graphs.
 """
 import torch
 import torch.distributed as dist
@@ -25,12 +30,12 @@ ALIGN = int(os.environ.get('TD_FLAT_ALIGN', '8'))      # elements: 16 B in bf16,
 
 class FlatMixedPrecision:
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None,
-                 lowp_dtype=torch.bfloat16, process_group=None, bucket_bytes=64 << 20):
+                 lowp_dtype=torch.bfloat16, process_group=None, bucket_bytes=64 << 20, lowp=None):
         params = [p for p in model.parameters() if p.requires_grad]
         dev = params[0].device
         lowp_ids = set()
         for m in model.modules():
-            if isinstance(m, nn.Conv2d) and os.environ.get('TD_FLAT_LOWP', '1') == '1':
+            if isinstance(m, nn.Conv2d) and (os.environ.get('TD_FLAT_LOWP', '1') == '1' if lowp is None else lowp):
                 for p in m.parameters(recurse=False):
                     if p.requires_grad:
                         lowp_ids.add(id(p))
