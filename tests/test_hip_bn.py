@@ -95,10 +95,12 @@ def test_join_channels_matches_cat(shape, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
-def test_grouped_batchnorm_equals_separate_passes(relu, with_res, dtype):
+@pytest.mark.parametrize("dims", [(3, 4, 128, 9, 13), (2, 2, 64, 96, 160)])     # small (merged finalize) / large tensors
+def test_grouped_batchnorm_equals_separate_passes(relu, with_res, dtype, dims):
     """groups=G on a stacked batch == G separate calls (statistics per pass, running stats updated in order,
     weight gradients summed): the pose pairs / source-frame features of mono_fm_joint/net.py:172-178, :221."""
-    dev, G, N, C, H, W = torch.device("cuda"), 3, 4, 128, 9, 13
+    dev = torch.device("cuda")
+    G, N, C, H, W = dims
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     g = torch.Generator().manual_seed(3)
     x = cl((torch.randn(G * N, C, H, W, generator=g) * torch.linspace(0.5, 2.0, G).repeat_interleave(N)[:, None, None, None]).to(dev).to(dtype))
