@@ -96,9 +96,9 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
     // coefficient row k (padded row r = y0-1+k) is consumed in iteration k;
     // the warp of gradient row q = r-1 is consumed in the same iteration.
     float dv[4], dv_n[4], ul0, ul1, ul0_n, ul1_n;
-    Tap tap;
-    TapVals tv[3];
-    float yq[3], depth_q, cf_n[9], m_n, mq_n;
+    Tap tap = {};
+    TapVals tv[3] = {};
+    float yq[3], depth_q = 0.f, cf_n[9], m_n, mq_n;
     auto issue_disp = [&](int q, float* d4, float& l0, float& l1) {        // gradient row q (clamped)
       const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
       const UpIdx uy = up_index(qc, ratio_y, a.hs);
@@ -122,14 +122,18 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
 #pragma unroll
       for (int c = 0; c < 3; ++c) yq[c] = tgtb[c * plane + offq];
       mq_n = (q >= 0 && q < H && (int)amb[offq] == sel) ? g_l1 : 0.f;
-      const float dd = l0 * (ux.l0 * d4[0] + ux.l1 * d4[1]) + l1 * (ux.l0 * d4[2] + ux.l1 * d4[3]);
-      depth_q = fast_rcp(a.min_disp + a.disp_range * dd);
-      const float fy = (float)qc;
-      float pt[3], cz[3];
-      tap = project_ray(rx0 + ik[1] * fy + ik[2], rx1 + ik[4] * fy + ik[5], rx2 + ik[7] * fy + ik[8], P, depth_q,
-                        W, H, pt, cz);
+      // rows k = 0, 1 only feed the vertical window of the coefficient sums: their warp (q above the chunk) is
+      // never consumed, so the projection and the 12 gathers are skipped (k is wave-uniform: a scalar branch)
+      if (k >= 2) {
+        const float dd = l0 * (ux.l0 * d4[0] + ux.l1 * d4[1]) + l1 * (ux.l0 * d4[2] + ux.l1 * d4[3]);
+        depth_q = fast_rcp(a.min_disp + a.disp_range * dd);
+        const float fy = (float)qc;
+        float pt[3], cz[3];
+        tap = project_ray(rx0 + ik[1] * fy + ik[2], rx1 + ik[4] * fy + ik[5], rx2 + ik[7] * fy + ik[8], P, depth_q,
+                          W, H, pt, cz);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) tv[c] = load_taps(srcb + c * plane, W, tap);
+        for (int c = 0; c < 3; ++c) tv[c] = load_taps(srcb + c * plane, W, tap);
+      }
     };
     issue_disp(y0 - 2, dv, ul0, ul1);                // q of k = 0
     issue_disp(y0 - 1, dv_n, ul0_n, ul1_n);          // q of k = 1
@@ -141,19 +145,22 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
       float cf[9], xq[3], yv[3], dxi[3], dyi[3];
 #pragma unroll
       for (int i = 0; i < 9; ++i) cf[i] = cf_n[i] * m_n;
-      const float ex = (float)tap.x0 + 1.f - tap.ix, wx = tap.ix - (float)tap.x0;
-      const float ey = (float)tap.y0 + 1.f - tap.iy, wy = tap.iy - (float)tap.y0;
-      const float mx = tap.gmx * sx_scale, my = tap.gmy * sy_scale;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        xq[c] = blend_taps(tv[c], tap);
-        yv[c] = yq[c];
-        const float vnw = tv[c].nw;
-        const float vne = tap.in_e ? tv[c].ne : 0.f;
-        const float vsw = tap.in_s ? tv[c].sw : 0.f;
-        const float vse = (tap.in_e && tap.in_s) ? tv[c].se : 0.f;
-        dxi[c] = (-vnw * ey + vne * ey - vsw * wy + vse * wy) * mx;     // d x_c / d u
-        dyi[c] = (-vnw * ex - vne * wx + vsw * ex + vse * wx) * my;     // d x_c / d v
+      for (int c = 0; c < 3; ++c) { xq[c] = 0.f; yv[c] = yq[c]; dxi[c] = 0.f; dyi[c] = 0.f; }
+      if (k >= 2) {                                   // rows above the chunk have no warp (see issue_row)
+        const float ex = (float)tap.x0 + 1.f - tap.ix, wx = tap.ix - (float)tap.x0;
+        const float ey = (float)tap.y0 + 1.f - tap.iy, wy = tap.iy - (float)tap.y0;
+        const float mx = tap.gmx * sx_scale, my = tap.gmy * sy_scale;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          xq[c] = blend_taps(tv[c], tap);
+          const float vnw = tv[c].nw;
+          const float vne = tap.in_e ? tv[c].ne : 0.f;
+          const float vsw = tap.in_s ? tv[c].sw : 0.f;
+          const float vse = (tap.in_e && tap.in_s) ? tv[c].se : 0.f;
+          dxi[c] = (-vnw * ey + vne * ey - vsw * wy + vse * wy) * mx;     // d x_c / d u
+          dyi[c] = (-vnw * ex - vne * wx + vsw * ex + vse * wx) * my;     // d x_c / d v
+        }
       }
       const float dq = depth_q, ml1 = mq_n;
       // ---- refill the pipeline (rows beyond the chunk are clamped duplicates, never consumed) ----
