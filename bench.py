@@ -245,7 +245,7 @@ def loss_path_time(cfg, batch, iters=20):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):      # same stream as the warm-up (see main)
         path()
     graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -369,15 +369,18 @@ def main():
             torch.cuda.synchronize()
         try:
             graph = torch.cuda.CUDAGraph()
+            # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes are bound to the stream
+            # of their first use, and a different capture stream would add an event fork/join per parameter
+            cap = side if os.environ.get("TD_CAPTURE_STREAM", "side") == "side" else None
             if not split_graph:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, stream=cap):
                     step()
                 graph.replay()
             else:
-                with torch.cuda.graph(graph, capture_error_mode=mode):
+                with torch.cuda.graph(graph, stream=cap, capture_error_mode=mode):
                     step.forward_backward()
                 graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, capture_error_mode=mode):
+                with torch.cuda.graph(graph_b, stream=cap, capture_error_mode=mode):
                     step.update()
                 graph.replay()
                 step.sync()
