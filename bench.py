@@ -328,8 +328,8 @@ def main():
     split_graph = (world > 1 or args.split_timing) and not use_syncbn and not args.no_graph
     # flat parameter store (tripled_amd/flat_amp.py).  N > 1: fp32 parameters, flat fp32 gradient buffer filled by
     # batched concatenations after backward -- no wrapper, no per-parameter accumulate kernels, the all-reduce runs
-    # on the flat buffer.  --flat: additionally a bf16 working copy of the conv weights (measured 2.1 ms/step SLOWER
-    # than plain autocast at C2; opt-in).
+    # on the flat buffer.  --flat: additionally a bf16 working copy of the conv weights (41.0 vs 41.3 ms/step at C2;
+    # opt-in until its checkpoint path exists).
     use_flat = dtype is not None and not use_syncbn and (args.flat or (world > 1 and not args.no_graph))
     if world > 1 and not use_flat:
         from mmcv.parallel import MMDistributedDataParallel
