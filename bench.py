@@ -23,6 +23,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Which stream the step graph is captured on.  "side" makes the graph one linear chain;
+# ROCm 7.2's AQL-packet-capture fast path for such graphs replays this 4 000-node step wrongly from the second
+# replay on (tools/diag_capture.py), so "side" is only used together with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0,
+# which must be in the environment before the HIP runtime initialises.
+CAPTURE_STREAM = os.environ.get("TD_CAPTURE_STREAM", "side")
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -31,6 +37,7 @@ import tripled_amd  # noqa: F401,E402
 from mmcv import Config  # noqa: E402
 from mono.datasets.synthetic import synthetic_batch  # noqa: E402
 from mono.model import MONO  # noqa: E402
+from tripled_amd.step import NonFiniteLossError, TrainStep, capture_step, warm_up  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 # algorithmic bytes per full-resolution pixel of one fused photometric launch at scale s
@@ -75,66 +82,6 @@ def build_model(cfg, device, channels_last):
         model = model.to(memory_format=torch.channels_last)
     model.train()
     return model
-
-
-class TrainStep:
-    """zero-grad -> forward -> sum of loss means -> backward -> clip -> Adam (what the Runner's
-    batch_processor + DistOptimizerHook do per iteration, mono/apis/trainer.py:32-60,
-    mono/core/utils/dist_utils.py:54-60)."""
-
-    def __init__(self, model, cfg, batch, autocast_dtype, flat=False):
-        self.model, self.batch, self.dtype = model, batch, autocast_dtype
-        inner = model.module if hasattr(model, "module") else model
-        self.params = [p for p in inner.parameters() if p.requires_grad]
-        ocfg = dict(cfg.optimizer)
-        assert ocfg.pop("type") == "Adam"
-        clip = cfg.optimizer_config.get("grad_clip", None)
-        self.max_norm = clip["max_norm"] if clip else None
-        self.reducer = getattr(model, "reducer", None)
-        self.flat = None
-        on_gpu = batch["K"].is_cuda
-        if flat:
-            from tripled_amd.flat_amp import FlatMixedPrecision
-            self.flat = FlatMixedPrecision(inner, max_norm=self.max_norm, lowp=flat == "lowp", **ocfg)
-            self.optimizer = self.flat.optimizer
-        else:
-            # fused multi-tensor Adam on the GPU (same update rule as torch.optim.Adam(lr, weight_decay=0))
-            self.optimizer = torch.optim.Adam(self.params, capturable=on_gpu, fused=on_gpu, **ocfg)
-        self.loss = None
-
-    def forward_backward(self):
-        if self.flat is not None:
-            self.flat.zero_grad()
-        elif self.reducer is None:
-            self.optimizer.zero_grad(set_to_none=True)   # with the DP engine, forward() re-zeroes the flat buffer
-        with torch.autocast("cuda" if self.batch["K"].is_cuda else "cpu", dtype=self.dtype,
-                            enabled=self.dtype is not None):
-            outputs, losses = self.model(dict(self.batch))
-        total = sum(v.float().mean() for v in losses.values())
-        total.backward()
-        if self.flat is not None:
-            self.flat.collect()
-        self.loss = total.detach()
-
-    def sync(self):
-        if self.flat is not None:
-            self.flat.allreduce()
-        elif self.reducer is not None and not self.reducer.overlap:
-            self.reducer.allreduce_all()
-
-    def update(self):
-        if self.flat is not None:
-            self.flat.step()
-            return
-        if self.max_norm is not None:
-            torch.nn.utils.clip_grad_norm_(self.params, self.max_norm, norm_type=2, foreach=True)
-        self.optimizer.step()
-
-    def __call__(self):
-        self.forward_backward()
-        self.sync()
-        self.update()
-        return self.loss
 
 
 def time_kernel(fn, iters=20, warm=3):
@@ -245,7 +192,7 @@ def loss_path_time(cfg, batch, iters=20):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):      # same stream as the warm-up (see main)
+    with torch.cuda.graph(graph, stream=side if CAPTURE_STREAM == "side" else None):
         path()
     graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -351,14 +298,10 @@ def main():
 
     # warm-up (and capture) on a side stream: autograd's AccumulateGrad nodes then belong to a
     # non-default stream, which whole-step graph capture requires
-    graph, graph_b, graphed = None, None, False
+    graphed_step, graphed = None, False
     side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(args.warmup, 1)):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
+    warm_up(step, max(args.warmup, 1), side)
+    loss_after_warmup = step.check_finite("warm-up")
     if not args.no_graph and (world == 1 or split_graph):
         # N > 1: every collective of the warm-up has completed (synchronize above) and the ranks line up before
         # capturing; "thread_local" keeps the process group's watchdog thread (event queries) from
@@ -367,32 +310,21 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+        # capture stream: see DESIGN.md section 6 ("side" = the warm-up stream, a linear single-stream graph;
+        # "default" = PyTorch's capture stream, one event fork/join per parameter gradient)
+        cap = side if CAPTURE_STREAM == "side" else None
         try:
-            graph = torch.cuda.CUDAGraph()
-            # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes are bound to the stream
-            # of their first use, and a different capture stream would add an event fork/join per parameter
-            cap = side if os.environ.get("TD_CAPTURE_STREAM", "side") == "side" else None
-            if not split_graph:
-                with torch.cuda.graph(graph, stream=cap):
-                    step()
-                graph.replay()
-            else:
-                with torch.cuda.graph(graph, stream=cap, capture_error_mode=mode):
-                    step.forward_backward()
-                graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_b, stream=cap, capture_error_mode=mode):
-                    step.update()
-                graph.replay()
-                step.sync()
-                graph_b.replay()
-            torch.cuda.synchronize()
+            graphed_step = capture_step(step, stream=cap, split=split_graph, capture_error_mode=mode)
             graphed = True
+        except NonFiniteLossError:
+            raise
         except Exception as e:      # capture is an optimisation; report and continue eagerly
             if rank == 0:
                 print("HIP graph capture unavailable (%s: %s); timing eager launches" % (type(e).__name__, e),
                       file=sys.stderr)
-            graph = graph_b = None
             torch.cuda.synchronize()
+    graph = graphed_step.graph if graphed else None
+    graph_b = graphed_step.graph_b if graphed else None
 
     if graphed and args.split_timing and rank == 0:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -404,13 +336,7 @@ def main():
             tb += ev[1].elapsed_time(ev[2]) / 10
         print("split timing: forward+backward(+gather) graph %.3f ms, sync+clip+Adam graph %.3f ms" % (ta, tb),
               file=sys.stderr)
-    if graphed and split_graph:
-        def run():
-            graph.replay()
-            step.sync()
-            graph_b.replay()
-    else:
-        run = graph.replay if graphed else step
+    run = graphed_step if graphed else step
     if args.h2d:
         # PCIe-inclusive variant: every step first copies the batch from pinned host
         # memory into the step's input buffers (the headline `value` is measured without this flag)
@@ -435,7 +361,14 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(step.loss)
+    # a benchmark of a numerically broken step is not a benchmark: non-finite loss or parameters -> exit code 3
+    try:
+        final_loss = step.check_finite("after the %d timed steps" % args.steps)
+    except NonFiniteLossError as e:
+        print("bench.py: INVALID RUN: %s" % e, file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -454,7 +387,8 @@ def main():
                                                           if graphed else ("bucketed RCCL all-reduce after backward" if use_flat
                                                                            else "bucketed RCCL all-reduce overlapped with backward"))),
                 "h2d_in_step": bool(args.h2d), "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
-                "final_loss": round(final_loss, 6)},
+                "capture_stream": CAPTURE_STREAM if graphed else None,
+                "loss_after_warmup": round(loss_after_warmup, 6), "final_loss": round(final_loss, 6), "valid": True},
         }
         if not args.no_roofline:
             kern = roofline_of_hot_kernels(cfg, batch)
@@ -488,7 +422,7 @@ def main():
                                      "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                      "what": "reference-algorithmic conv FLOPs (SURVEY section 6) / whole step time"}
         if world == 1 and not args.no_cpu_baseline:
-            del model, step, graph
+            del model, step, graph, graph_b, graphed_step, run
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# see tripled_amd/__init__.py: must be in the environment before the HIP runtime initialises
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

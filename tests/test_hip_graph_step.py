@@ -1,0 +1,180 @@
+"""The benchmarked configuration, tested: cfg_kitti_tripleD (ResNet50, B=12, 192x640) under bf16 autocast +
+channels_last with the hand-written kernels, stepped K times (a) eagerly and (b) from the HIP graph exactly
+as bench.py captures it (tripled_amd.step.capture_step), from identical weights, optimiser state, inputs and
+RNG state.  Reference step semantics: mono/core/utils/dist_utils.py:54-60 (zero_grad, backward, clip, step)
+around mono/model/mono_fm_joint_inpaint/net.py:477-518 (forward).
+
+Two comparisons, tolerances stated:
+
+1. SAME-STATE (tight).  Before replay i the weights, BatchNorm buffers, Adam state and RNG offset are reset
+   to what the eager run had before its step i.  The replay then executes the same kernels on the same data;
+   what remains is order-dependent f32 accumulation (MIOpen's split-K implicit-GEMM kernels use atomics, so
+   even two EAGER forwards from the same state differ: measured 3 % (scale 0) to 36 % (scale 3) of the bf16
+   disparity pixels off by one ulp, loss entries off by up to 7e-4 relative).  Every loss_dict entry must agree
+   to 1e-5 + 3e-3 relative, the bf16 disparities to max 2 ulp and mean 0.5 ulp.  The parameters after the update
+   must agree with the eager run's next state to max |delta| <= 2.5 * lr (Adam's first updates are
+   ~lr * sign(g): a noise-level gradient entry can flip a whole update; measured 1.3-1.6 lr) and mean
+   |delta| <= 0.25 * lr (measured 0.03-0.06 lr).  The same bounds are asserted eager-vs-eager (noise floor:
+   measured values are the same as graph-vs-eager, tools/diag_capture.py and gpurun logs of round 2).
+2. FREE-RUNNING (loose).  K consecutive replays against K consecutive eager steps: the atomics noise is
+   amplified by the sign-like Adam updates through ~100 bf16 layers, so the trajectories separate at the
+   bf16-ulp level (ulp = 2^-8 near disp = 1).  Asserted at every step: every loss entry within 2e-3 + 2 %, total
+   within 2e-3, mean |disp difference| < 2 ulp at every scale.  The same bound is asserted between two EAGER
+   runs (the noise floor), so the tolerance is the path's own run-to-run spread, not slack for the graph.
+
+Plus: zero ATen fallbacks (strict mode), all parameters finite after 25 further replays.
+"""
+import copy
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K_STEPS = 4
+ULP = 2.0 ** -8
+
+
+def _build(cfg_name="cfg_kitti_tripleD.py", **over):
+    import tripled_amd  # noqa: F401
+    from mmcv import Config
+    from mono.datasets.synthetic import synthetic_batch
+    from mono.model import MONO
+    from tripled_amd.step import TrainStep
+    cfg = Config.fromfile(os.path.join(ROOT, "config", cfg_name))
+    for k, v in over.items():
+        cfg.model[k] = v
+    m = cfg.model
+    torch.backends.cudnn.benchmark = False      # no MIOpen find: keeps the test to ~1 minute
+    torch.manual_seed(1024)
+    dev = torch.device("cuda", 0)
+    model = MONO.module_dict[m["name"]](m).to(dev).to(memory_format=torch.channels_last)
+    model.train()
+    batch = synthetic_batch(m["imgs_per_gpu"], m["height"], m["width"], seed=1000, device=dev,
+                            frame_ids=tuple(m["frame_ids"]))
+    return cfg, model, TrainStep(model, cfg, batch, torch.bfloat16)
+
+
+def _snapshot(model, step):
+    return (copy.deepcopy(model.state_dict()), copy.deepcopy(step.optimizer.state_dict()),
+            torch.cuda.get_rng_state())
+
+
+def _restore(model, step, snap):
+    sd, osd, rng = snap
+    with torch.no_grad():
+        cur = model.state_dict()
+        for k, v in sd.items():
+            cur[k].copy_(v)                       # in place: the graph holds these addresses
+        for group_state, saved in zip(step.optimizer.state.values(), osd["state"].values()):
+            for k, v in saved.items():
+                if torch.is_tensor(v):
+                    group_state[k].copy_(v)
+    torch.cuda.set_rng_state(rng)
+    torch.cuda.synchronize()
+
+
+def _record(step, n_scales=4):
+    torch.cuda.synchronize()
+    return ({str(k): float(v) for k, v in step.losses.items()}, float(step.loss),
+            [step.outputs[("disp", 0, s)].float().cpu().clone() for s in range(n_scales)])
+
+
+def _compare_loose(tag, ref, got):
+    for i, ((l_r, t_r, d_r), (l_g, t_g, d_g)) in enumerate(zip(ref, got)):
+        assert l_r.keys() == l_g.keys()
+        assert abs(t_r - t_g) < 2e-3, (tag, i, t_r, t_g)
+        for k in l_r:
+            assert abs(l_r[k] - l_g[k]) < 2e-3 + 2e-2 * abs(l_r[k]), (tag, i, k, l_r[k], l_g[k])
+        for s, (a, b) in enumerate(zip(d_r, d_g)):
+            assert float((a - b).abs().mean()) < 2 * ULP, (tag, i, s, float((a - b).abs().mean()))
+
+
+def _compare_tight(tag, i, ref, got):
+    (l_r, t_r, d_r), (l_g, t_g, d_g) = ref, got
+    worst = max(abs(l_r[k] - l_g[k]) / (1e-5 + abs(l_r[k])) for k in l_r)
+    frac = [float(((a - b).abs() > 0).float().mean()) for a, b in zip(d_r, d_g)]
+    dmax = [float((a - b).abs().max()) / ULP for a, b in zip(d_r, d_g)]
+    print("[%s same-state %d] worst loss-entry rel diff %.2e, disp pixels differing %s, max diff (ulp) %s" % (
+        tag, i, worst, ["%.4f" % f for f in frac], dmax))
+    if os.environ.get("TD_CALIBRATE"):
+        return
+    for k in l_r:
+        assert abs(l_r[k] - l_g[k]) < 1e-5 + 3e-3 * abs(l_r[k]), (tag, i, k, l_r[k], l_g[k])
+    for s, (a, b) in enumerate(zip(d_r, d_g)):
+        d = (a - b).abs()
+        assert float(d.max()) <= 2 * ULP + 1e-7, (tag, i, s, float(d.max()))
+        assert float(d.mean()) < 0.5 * ULP, (tag, i, s, float(d.mean()) / ULP)
+
+
+def _param_delta(model, sd):
+    cur = model.state_dict()
+    mx, tot, n = 0.0, 0.0, 0
+    for k, p in model.named_parameters():
+        d = (cur[k].float() - sd[k].float()).abs()
+        mx = max(mx, float(d.max()))
+        tot += float(d.sum())
+        n += d.numel()
+    return mx, tot / n
+
+
+@pytest.mark.parametrize("capture", ["side", "default"])
+def test_graph_replay_matches_eager_c2(capture):
+    from tripled_amd import dispatch
+    from tripled_amd.step import capture_step, warm_up
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    cfg, model, step = _build()
+    lr = cfg.optimizer["lr"]
+    dispatch.reset()
+    side = torch.cuda.Stream()
+    with dispatch.strict():
+        warm_up(step, 2, side)
+    assert sum(dispatch.fallbacks.values()) == 0, dict(dispatch.fallbacks)
+    assert dispatch.hip_calls["td_photo_fwd"] == 2 * 4 and dispatch.hip_calls["td_bn_fwd"] > 100
+
+    snaps, eager = [_snapshot(model, step)], []
+    for _ in range(K_STEPS):
+        warm_up(step, 1, side)
+        eager.append(_record(step))
+        snaps.append(_snapshot(model, step))
+    step.check_finite("eager")
+
+    if capture == "side":                          # noise floor of the free-running comparison
+        _restore(model, step, snaps[0])
+        eager2 = []
+        for _ in range(K_STEPS):
+            warm_up(step, 1, side)
+            eager2.append(_record(step))
+        _compare_loose("eager-vs-eager", eager, eager2)
+        for i in range(K_STEPS):                   # ... and of the same-state comparison
+            _restore(model, step, snaps[i])
+            warm_up(step, 1, side)
+            _compare_tight("eager-vs-eager", i, eager[i], _record(step))
+
+    _restore(model, step, snaps[0])
+    graphed = capture_step(step, stream=side if capture == "side" else None, validate=False)
+
+    # 1. same-state replays
+    for i in range(K_STEPS):
+        _restore(model, step, snaps[i])
+        graphed()
+        _compare_tight(capture, i, eager[i], _record(step))
+        mx, mean = _param_delta(model, snaps[i + 1][0])
+        print("[%s same-state %d] parameters after the update vs eager: max %.2f lr, mean %.4f lr" % (capture, i, mx / lr, mean / lr))
+        assert mx <= 2.5 * lr and mean <= 0.25 * lr, (capture, i, mx / lr, mean / lr)
+
+    # 2. free-running replays
+    _restore(model, step, snaps[0])
+    replayed = []
+    for _ in range(K_STEPS):
+        graphed()
+        replayed.append(_record(step))
+    step.check_finite("graph replay")
+    assert abs(replayed[0][1] - replayed[-1][1]) > 1e-4      # the trajectory moves (a frozen graph is also "finite")
+    _compare_loose(capture, eager, replayed)
+    # a longer replay stays finite (the ROCm packet-capture corruption appeared between replay 1 and 20)
+    for _ in range(25):
+        graphed()
+    step.check_finite("25 more replays")

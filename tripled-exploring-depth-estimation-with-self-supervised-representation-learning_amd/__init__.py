@@ -19,6 +19,13 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 HOSTSIDE = os.path.join(PKG_DIR, "hostside")
 
 
+# ROCm 7.2's hipGraph AQL-packet-capture fast path replays a single-stream capture of the ~4 000-node training
+# step wrongly (garbage loss terms / NaN gradients from the second replay on, tools/diag_capture.py, DESIGN.md
+# section 6); the general replay path is correct.  The flag is read when the HIP runtime initialises, so it is
+# set on import of this package (before any HIP call); an explicit setting in the environment wins.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
 def _activate():
     if HOSTSIDE not in sys.path:
         sys.path.insert(0, HOSTSIDE)

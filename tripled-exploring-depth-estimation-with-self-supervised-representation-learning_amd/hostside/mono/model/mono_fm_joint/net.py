@@ -160,6 +160,8 @@ class mono_fm_joint(nn.Module):
             if ops.featreg_supported(feature) and img.shape[2] % h == 0 and img.shape[3] % w == 0:
                 # fused HIP path: reads the (bf16/f32, channels-last) feature map directly
                 return ops.feature_regularization(feature, ops.area_downsample(img, h, w), self.opt.dis, self.opt.cvt)
+            from tripled_amd import dispatch
+            dispatch.fallback("feature_regularization", "dtype %s, shape %s" % (feature.dtype, tuple(feature.shape)))
         feature = feature.float()
         img = F.adaptive_avg_pool2d(img, feature.shape[2:])
         f_dx, f_dy = self.gradient(feature)

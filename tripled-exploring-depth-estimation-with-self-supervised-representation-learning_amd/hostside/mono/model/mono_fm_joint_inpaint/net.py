@@ -65,6 +65,8 @@ class mono_fm_joint_inpaint(mono_fm_joint):
         else:
             src_f = [self._source_features(img) for img in imgs]
         if not ops.featwarp_supported(tgt_f, src_f):
+            from tripled_amd import dispatch
+            dispatch.fallback("feature_metric_warp", "dtype %s, shape %s" % (tgt_f.dtype, tuple(tgt_f.shape)))
             return None
         K = inputs["K"].float().clone()
         K[:, 0:2, :] = K[:, 0:2, :] / 2
@@ -88,6 +90,9 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             from tripled_amd import ops
             loss = ops.masked_reconstruction_sum(res_img, t_rs, hole.sum(1)) / torch.sum(hole)
         else:
+            if res_img.is_cuda:
+                from tripled_amd import dispatch
+                dispatch.fallback("masked_reconstruction", "size %s" % (size,))
             loss = self.compute_reprojection_loss(res_img, t_rs)
             loss = torch.sum(loss * hole) / torch.sum(hole)
         return loss / len(opt.scales) * opt.get("img_reconstruct_weight", 1)

@@ -26,6 +26,25 @@ def _ops():
     return ops
 
 
+def _dense_cl(x):
+    """A HIP activation whose channels are a multiple of 8 but which is a strided view (e.g. the channel halves
+    the disentangled model cuts out of the scene embedding, mono_fm_joint_inpaint/net.py:488-492) is packed into
+    dense channels-last memory so that the hand-written kernels take it; everything else is returned as is."""
+    if x.is_cuda and x.dim() == 4 and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
+            and not x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1:
+        return x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
+def _fell_back(site, x, why=""):
+    """An activation that lives on a HIP device takes an ATen composition instead of the hand-written kernel
+    (tripled_amd.dispatch: counted; raises in strict mode).  CPU tensors are not reported."""
+    if x.is_cuda:
+        from tripled_amd import dispatch
+        dispatch.fallback(site, why or "dtype %s, shape %s, channels_last %s" % (
+            x.dtype, tuple(x.shape), x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)))
+
+
 class BatchNorm(nn.BatchNorm2d):
     """nn.BatchNorm2d with the per-layer ``num_batches_tracked += 1`` taken out of forward().  The
     counter is not used by the computation when momentum is a number (0.1 here); bumping 252 of them
@@ -52,6 +71,7 @@ class BatchNorm(nn.BatchNorm2d):
             if self._hip_ok(x):
                 return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                             self.momentum, self.eps, groups=g)
+            _fell_back("BatchNorm", x)
             if g > 1:      # stacked passes without the HIP kernels: one ATen call per pass, in order
                 return torch.cat([F.batch_norm(c, self.running_mean, self.running_var, self.weight, self.bias, True,
                                                self.momentum, self.eps) for c in x.chunk(g, 0)], 0)
@@ -66,7 +86,7 @@ class BatchNorm(nn.BatchNorm2d):
             self._pending += g
             return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                         self.momentum, self.eps, residual=residual, relu=relu, groups=g)
-        return _plain_bn_act(self, x, residual, relu)
+        return _plain_bn_act(self, x, residual, relu)      # (BatchNorm.forward reports the fallback)
 
 
 _BN_GROUPS = [1]
@@ -223,6 +243,7 @@ class ResNet(nn.Module):
         if x.is_cuda and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
                 and x.is_contiguous(memory_format=torch.channels_last) and not os.environ.get("TD_NO_HIP_STEM_POOL"):
             return _ops().maxpool3s2(x)
+        _fell_back("ResNet.maxpool", x)
         return self.maxpool(x)
 
     def pyramid(self, x, extra=None):
@@ -413,10 +434,13 @@ class Conv3x3(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
     def _pad_input(self, x):
+        x = _dense_cl(x)
         if self.use_refl and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] >= 2 and x.shape[3] >= 2:
             from tripled_amd import ops          # gather-form pad / adjoint (ATen's backward uses atomics)
             return ops.reflpad1(x)
+        if self.use_refl:
+            _fell_back("Conv3x3.pad", x)
         return self.pad(x)
 
     def forward(self, x):
@@ -446,10 +470,12 @@ class Conv3x3(nn.Module):
     def forward_up(self, x):
         """self(upsample(x)): x2 nearest + reflection pad in one HIP pass when the layout allows it."""
         cin = self.conv.weight.shape[1]
+        x = _dense_cl(x)
         if (self.use_refl and x.is_cuda and x.shape[1] == cin and cin % 8 == 0 and self.conv.weight.shape[0] % 8 == 0
                 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous(memory_format=torch.channels_last)
                 and not os.environ.get("TD_NO_FUSED_UPSAMPLE")):
             return self.conv(_ops().up2_reflpad1(x))
+        _fell_back("Conv3x3.forward_up", x)
         return self.forward(upsample(x))
 
 
@@ -497,6 +523,7 @@ class CRPBlock(nn.Module):
                 and t.dtype in (torch.float32, torch.bfloat16):
             from tripled_amd import ops
             return ops.maxpool5(t)
+        _fell_back("CRPBlock.maxpool", t)
         return self.maxpool(t)
 
     def forward(self, x):
@@ -517,6 +544,7 @@ class ReflPad1(nn.ReflectionPad2d):
         if x.is_cuda and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16) \
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] >= 2 and x.shape[3] >= 2:
             return _ops().reflpad1(x)
+        _fell_back("ReflPad1", x)
         return super().forward(x)
 
 
@@ -583,6 +611,7 @@ class DepthDecoder(nn.Module):
             if x.is_cuda and c % 8 and x.dtype == torch.bfloat16 and not os.environ.get("TD_NO_CHANNEL_PAD"):
                 if _round8(c) == r.shape[1] + x.shape[1] + 8 and _ops().join_channels_supported(*parts):
                     return _ops().join_channels(*parts)        # one HIP pass (ATen cat: 528 us at 48x160)
+                _fell_back("DepthDecoder.join", x)
                 # 513 -> 520 zero channels: see Conv3x3
                 parts.append(x.new_zeros(x.shape[0], _round8(c) - c, x.shape[2], x.shape[3]))
             return torch.cat(parts, 1)

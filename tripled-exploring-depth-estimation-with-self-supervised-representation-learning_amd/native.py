@@ -8,6 +8,8 @@ import os
 
 import torch
 
+from . import dispatch
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtripled_hip.so")
 
@@ -100,6 +102,7 @@ def load(path=None):
 
 
 def check(code, what):
+    dispatch.hip(what)
     if code != 0:
         lib = load()
         msg = lib.td_error_string(code).decode()
