@@ -37,6 +37,7 @@ import tripled_amd  # noqa: F401,E402
 from mmcv import Config  # noqa: E402
 from mono.datasets.synthetic import synthetic_batch  # noqa: E402
 from mono.model import MONO  # noqa: E402
+from tripled_amd import dispatch  # noqa: E402
 from tripled_amd.step import NonFiniteLossError, TrainStep, capture_step, warm_up  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
@@ -66,6 +67,8 @@ def parse():
     p.add_argument("--split-timing", action="store_true", help="two graphs (fwd+bwd | clip+Adam) and report each")
     p.add_argument("--flat", action="store_true", help="flat bf16/fp32 parameter store (tripled_amd/flat_amp.py) instead of autocast + per-parameter Adam")
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
+    p.add_argument("--allow-fallbacks", action="store_true",
+                   help="do not fail when a HIP-resident tensor takes an ATen composition instead of a hand-written kernel")
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--syncbn", default="off", choices=["on", "off"],
@@ -300,7 +303,11 @@ def main():
     # non-default stream, which whole-step graph capture requires
     graphed_step, graphed = None, False
     side = torch.cuda.Stream()
+    # strict dispatch: any layer of the step that would silently route a HIP tensor to an ATen composition raises
+    dispatch.reset()
+    dispatch.set_strict(not args.allow_fallbacks)
     warm_up(step, max(args.warmup, 1), side)
+    td_calls_per_step = sum(dispatch.hip_calls.values()) // max(args.warmup, 1)
     loss_after_warmup = step.check_finite("warm-up")
     if not args.no_graph and (world == 1 or split_graph):
         # N > 1: every collective of the warm-up has completed (synchronize above) and the ranks line up before
@@ -388,6 +395,7 @@ def main():
                                                                            else "bucketed RCCL all-reduce overlapped with backward"))),
                 "h2d_in_step": bool(args.h2d), "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
                 "capture_stream": CAPTURE_STREAM if graphed else None,
+                "fallbacks": sum(dispatch.fallbacks.values()), "td_abi_calls_per_step": td_calls_per_step,
                 "loss_after_warmup": round(loss_after_warmup, 6), "final_loss": round(final_loss, 6), "valid": True},
         }
         if not args.no_roofline:
