@@ -14,7 +14,7 @@ data = dict(
     name="kitti", split="exp", height=HEIGHT, width=WIDTH, frame_ids=FRAME_IDS,
     in_path=os.environ.get("KITTI_RAW", "/data/kitti_raw"),
     gt_depth_path=os.environ.get("KITTI_GT_DEPTHS", "/data/kitti_raw/gt_depths.npz"),
-    png=True, stereo_scale=STEREO, allow_synthetic=True, synthetic_length=2 * 32,
+    png=True, stereo_scale=STEREO, allow_synthetic=os.environ.get("TD_ALLOW_SYNTHETIC", "0") == "1", synthetic_length=2 * 32,
 )
 
 model = dict(

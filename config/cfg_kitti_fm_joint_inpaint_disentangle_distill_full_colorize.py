@@ -16,7 +16,7 @@ data = dict(
     gt_depth_path=os.environ.get("KITTI_GT_DEPTHS", "/data/kitti_raw/gt_depths.npz"),
     png=True, stereo_scale=STEREO, erase_shape=[16, 16], erase_count=16,
     map_cfg=dict(alphas=[0.1, 0.4, 0.7, 1.0], blur_kernel_size=(9, 9), map_n=2),
-    allow_synthetic=True, synthetic_length=8 * 64,
+    allow_synthetic=os.environ.get("TD_ALLOW_SYNTHETIC", "0") == "1", synthetic_length=8 * 64,
 )
 
 model = dict(

@@ -2,7 +2,8 @@
 # feature networks, ResNet18 pose network.  Same keys as the reference's cfg_kitti_tripleD.py
 # (which ships 320x1024 / 3 per GPU -- change the three constants below to reproduce it).
 # No pre-trained weights or KITTI data are available offline: the *_pretrained_path entries are
-# None and the data section falls back to synthetic triplets when in_path does not exist.
+# None and the data section falls back to synthetic triplets when in_path does not exist AND TD_ALLOW_SYNTHETIC=1
+# is set (offline smoke runs); otherwise a missing KITTI path is an error, as in the reference.
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,7 @@ data = dict(
     in_path=os.environ.get("KITTI_RAW", "/data/kitti_raw"),
     gt_depth_path=os.environ.get("KITTI_GT_DEPTHS", "/data/kitti_raw/gt_depths.npz"),
     png=True, stereo_scale=STEREO, erase_shape=[16, 16], erase_count=16,
-    allow_synthetic=True, synthetic_length=12 * 64,
+    allow_synthetic=os.environ.get("TD_ALLOW_SYNTHETIC", "0") == "1", synthetic_length=12 * 64,
 )
 
 model = dict(

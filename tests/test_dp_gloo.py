@@ -64,7 +64,7 @@ def _worker(rank, world, port, out_dir):
     (local(x) - y).pow(2).mean().backward()
     for (n, p), q in zip(net.named_parameters(), local.parameters()):
         if q.grad is None:
-            assert float(p.grad.abs().max()) == 0.0, n
+            assert p.grad is None, n      # unused parameter: left without a gradient, the optimiser skips it (as torch DDP)
             continue
         t = q.grad.clone()
         dist.all_reduce(t)

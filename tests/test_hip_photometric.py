@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import geometry, photometric  # noqa: E402
-from tests.util import kitti_K, make_triplet, random_poses, rel_err, smooth_image  # noqa: E402
+from tests.util import assert_argmin_parity, kitti_K, make_triplet, random_poses, rel_err, smooth_image  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -62,7 +62,8 @@ def test_forward_matches_oracle(ops, B, H, W, hs, ws, automask):
     for i in range(2):
         # coordinate rounding (ulp(x) ~ 1.5e-5 at x = 200) times image slope
         assert float((warped[i].cpu() - ref_warped[i]).abs().max()) < 1e-4
-    assert (argmin.cpu().long() == ref_idx).float().mean() > 0.995
+    _, _, stack = photometric.min_reprojection(tgt, srcs, ref_warped, nz, automask)
+    assert_argmin_parity(argmin, ref_idx, stack)       # exact except at fp near-ties (< 2e-5 apart)
     assert abs(float(loss) - float(ref_loss)) < 2e-6 + 1e-5 * abs(float(ref_loss))
 
 
@@ -121,7 +122,8 @@ def test_against_reference_golden(ops, golden_dir, scale):
                                                       idl, noise.cuda(), 0.1, 100.0, 4, keep_warped=True)
     assert float((warped[0].cpu() - T(p + "warped_-1")).abs().max()) < 3e-5
     assert float((warped[1].cpu() - T(p + "warped_1")).abs().max()) < 3e-5
-    assert (argmin.cpu().numpy() == z[p + "min_index"]).mean() > 0.998
+    # reference torch.min indices over the reference's own candidate stack (mono_fm_joint_inpaint/net.py:114-117)
+    assert_argmin_parity(argmin, T(p + "min_index"), T(p + "cands"), max_frac=2e-3)
     assert abs(float(loss) - float(z[p + "loss"])) < 1e-6
     loss.backward()
     assert rel_err(d.grad, T(p + "d_disp")) < 5e-3
@@ -144,9 +146,10 @@ def test_full_size_properties(ops):
     l2, a2, _ = run()
     assert float(l1) == float(l2) and bool((a1 == a2).all())   # bit-reproducible
     nz = [noise[0].unsqueeze(1), noise[1].unsqueeze(1)]
-    ref_loss, ref_idx, _ = photometric.photometric_scale_loss(fr[0], [fr[-1], fr[1]], disp, K, invK, Ts, nz, 0.1, 100.0)
+    ref_loss, ref_idx, ref_warped = photometric.photometric_scale_loss(fr[0], [fr[-1], fr[1]], disp, K, invK, Ts, nz, 0.1, 100.0)
     assert abs(float(l1) - float(ref_loss)) < 1e-6
-    assert (a1.cpu().long() == ref_idx).float().mean() > 0.995
+    _, _, stack = photometric.min_reprojection(fr[0], [fr[-1], fr[1]], ref_warped, nz, True)
+    assert_argmin_parity(a1, ref_idx, stack)           # 1 474 560 pixels: exact except at fp near-ties
     eye = torch.eye(4).unsqueeze(0).repeat(B, 1, 1)
     Pid = _P(K, [eye, eye]).cuda()
     _, _, w = ops.photometric_scale_loss(torch.full((B, 1, 96, 320), 0.3).cuda(), Pid, tgt, srcs, invK.cuda(),

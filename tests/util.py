@@ -41,3 +41,24 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_argmin_parity(argmin, ref_idx, stack, tol=2e-5, max_frac=5e-3):
+    """Index work is held to exact agreement: ``argmin`` (kernel) must equal ``ref_idx`` (oracle/reference torch.min
+    over ``stack`` [B,n,H,W]) at every pixel, except where the two candidates involved are a floating-point near-tie,
+    |stack[argmin] - stack[ref_idx]| < tol (the kernel's candidates carry ~1e-5 of fp32 re-association error).
+    Also bounds the share of such pixels.  Returns that share."""
+    a = argmin.detach().cpu().long()
+    r = ref_idx.detach().cpu().long()
+    stack = stack.detach().cpu()
+    assert a.shape == r.shape and int(a.max()) < stack.shape[1]
+    diff = a != r
+    frac = float(diff.float().mean())
+    if diff.any():
+        ca = stack.gather(1, a.unsqueeze(1)).squeeze(1)
+        cr = stack.gather(1, r.unsqueeze(1)).squeeze(1)
+        gap = (ca - cr).abs()[diff]
+        assert float(gap.max()) < tol, "arg-min differs at %d pixels that are not near-ties (largest gap %.3e)" % (
+            int((gap >= tol).sum()), float(gap.max()))
+    assert frac <= max_frac, frac
+    return frac

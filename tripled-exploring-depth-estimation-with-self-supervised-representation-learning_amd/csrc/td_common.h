@@ -5,24 +5,15 @@
 
 #include "tripled_hip.h"
 
-// Photometric tiles: one 256-thread workgroup (4 waves) per TILE_H x TILE_W output pixels.
-// TILE_W = 64 puts one image row segment on one wave: global reads of a row are a single
-// 256-byte coalesced request and LDS rows are read conflict-free (consecutive banks).
+// Block size of the element-wise / gather kernels (4 waves).  The streaming photometric and reconstruction
+// kernels size their own blocks (one wave per column strip, see td_photo_fwd.hip).
 #define TD_THREADS 256
-#define TD_FWD_THREADS 512
-#define TD_TILE_W 64
-#define TD_FWD_TILE_H 16
-#define TD_BWD_TILE_H 8
 
 #define TD_SSIM_C1 ((float)(0.01 * 0.01))
 #define TD_SSIM_C2 ((float)(0.03 * 0.03))
 #define TD_L1_EPS2 ((float)(1e-3 * 1e-3))
 
 namespace td {
-
-struct LaunchStatus {
-  static int check(const char* what);
-};
 
 int record_launch_error(hipError_t e, const char* what);
 
@@ -57,12 +48,6 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
   __syncthreads();
   return r;
 }
-
-// Per-sample camera constants staged once per block.
-struct Cam {
-  float ik[9];                 // inv_K[:3,:3]
-  float P[TD_MAX_SRC][12];     // (K @ T_i)[:3,:]
-};
 
 // Result of projecting one target pixel into one source frame.
 struct Tap {
@@ -181,10 +166,6 @@ __device__ __forceinline__ float blend_taps(const TapVals& v, const Tap& t) {
   o += v.sw * t.sw;
   o += v.se * t.se;
   return o;
-}
-
-__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, int W, const Tap& t) {
-  return blend_taps(load_taps(plane, W, t), t);
 }
 
 // 1/x and sqrt(x) to ~1 ulp (v_rcp_f32 / v_sqrt_f32) for quantities whose conditioning does not

@@ -8,6 +8,7 @@ training step off the hand-written kernels (``bench.py`` runs strict and prints 
 """
 import collections
 import contextlib
+import logging
 import os
 
 
@@ -25,6 +26,9 @@ def hip(name, n=1):
 
 
 def fallback(site, why=""):
+    if not fallbacks[site]:      # once per site: a training run that is off the hand-written kernels says so in its log
+        logging.getLogger("tripled_amd").warning("%s: HIP tensor routed to ATen ops instead of the hand-written kernel%s",
+                                                 site, (" (" + why + ")") if why else "")
     fallbacks[site] += 1
     if _strict[0]:
         raise FallbackError("%s fell back to ATen ops%s (strict mode)" % (site, (": " + why) if why else ""))

@@ -79,7 +79,7 @@ class FlatMixedPrecision:
         self.max_norm = max_norm
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.use_avg = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self.use_avg = dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         per = max(1, bucket_bytes // 4)
         self.buckets = [(s, min(s + per, n_all)) for s in range(0, n_all, per)]
 
@@ -127,9 +127,10 @@ class FlatMixedPrecision:
             torch.cat(self._flat_sources(self.full, self.offsets[k:], self.flat_g.numel(), torch.float32),
                       out=self.flat_g[self.n_lp:])
 
-    def allreduce(self):
-        """Average flat_g over the ranks: a few large RCCL all-reduces, issued back to back."""
-        if self.world == 1:
+    def allreduce(self, force=False):
+        """Average flat_g over the ranks: a few large RCCL all-reduces, issued back to back.  A one-rank job skips
+        the collectives unless ``force`` (the single-GPU RCCL test of this path)."""
+        if self.world == 1 and not force:
             return
         works = []
         for s, e in self.buckets:
@@ -143,9 +144,11 @@ class FlatMixedPrecision:
 
     def step(self):
         """clip_grad_norm_(max_norm, 2) + Adam on the flat buffers, then refresh the bf16 working copy."""
+        total = None
         if self.max_norm is not None:
             total = torch.linalg.vector_norm(self.flat_g)
             self.flat_g.mul_(torch.clamp(self.max_norm / (total + 1e-6), max=1.0))
         self.optimizer.step()
         if self.n_lp:
             self.flat_lp.copy_(self.flat_w[:self.n_lp])
+        return total

@@ -58,6 +58,7 @@ class GradientBuckets:
         if members:
             self._close(start, off, members)
         self.pending = [0] * len(self.buckets)
+        self.arrived = set()       # parameters whose gradient was produced by the current backward
         self.launched = [False] * len(self.buckets)
         self.works = []
         self.callback_queued = False
@@ -84,6 +85,7 @@ class GradientBuckets:
             self.pending[i] = len(members)
             self.launched[i] = False
         self.works = []
+        self.arrived = set()
         self.callback_queued = False
         self.synced = False
 
@@ -108,6 +110,7 @@ class GradientBuckets:
         if not self.callback_queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finalize)
             self.callback_queued = True
+        self.arrived.add(p)
         i = self.bucket_of[p]
         self.pending[i] -= 1
         if self.pending[i] == 0 and not self.launched[i]:
@@ -123,6 +126,13 @@ class GradientBuckets:
             if not self.use_avg:
                 chunk.div_(self.world)
         self.works = []
+        if self.overlap:
+            # a parameter no gradient reached (on any rank: all ranks run the same graph) keeps .grad = None, as under
+            # torch DDP with find_unused_parameters=True, so the optimiser skips it instead of applying a
+            # zero-gradient step (which would still decay it under weight_decay / move Adam's moments)
+            for p in self.params:
+                if p not in self.arrived:
+                    p.grad = None
         self.synced = True
 
     def allreduce_all(self):
@@ -143,7 +153,8 @@ class MMDistributedDataParallel(nn.Module):
     broadcast_buffers=False, find_unused_parameters=...)``."""
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=False,
-                 find_unused_parameters=False, bucket_cap_mb=64, process_group=None, overlap=True, **kwargs):
+                 find_unused_parameters=False, bucket_cap_mb=64, process_group=None, overlap=True,
+                 engine_at_world_1=False, **kwargs):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("MMDistributedDataParallel needs an initialised process group (init_dist)")
@@ -155,7 +166,9 @@ class MMDistributedDataParallel(nn.Module):
         self.world = dist.get_world_size(process_group)
         self._sync_initial_state()
         self.reducer = None
-        if self.world > 1:
+        # engine_at_world_1: run the bucket engine (and its collectives) in a one-rank group too -- the single-GPU
+        # RCCL test of this code path; a real one-rank job skips it
+        if self.world > 1 or engine_at_world_1:
             self.reducer = GradientBuckets(list(module.parameters()), int(bucket_cap_mb * 1024 * 1024), process_group,
                                            overlap=overlap)
 

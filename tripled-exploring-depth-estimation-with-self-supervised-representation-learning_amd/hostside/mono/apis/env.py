@@ -1,73 +1,78 @@
-"""Process-group bring-up, seeding, logging (reference: mono/apis/env.py).  One process per GPU;
-backend 'nccl' on ROCm is RCCL over xGMI."""
+"""Rank bring-up for the one-process-per-GPU data-parallel run, plus seeding and the root logger.
+
+Public names and call signatures are the ones train.py uses (reference: mono/apis/env.py --
+``init_dist(launcher, backend, **kwargs)``, ``set_random_seed(seed)``, ``get_root_logger(log_level)``).
+The bring-up itself is written for this build's launch model: ``python -m torch.distributed.run`` (or any
+launcher that exports RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) starts one rank per MI355X;
+the rank binds its GPU FIRST and hands the bound device to the process group, so RCCL builds its xGMI
+communicator eagerly on the right device instead of guessing it at the first collective.
+"""
 import logging
 import os
 import random
-import subprocess
 
 import numpy as np
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
-from mmcv.runner import get_dist_info
+
+_LAUNCHERS = ("pytorch",)
+
+
+class RankEnv:
+    """The launcher-provided coordinates of this process."""
+
+    def __init__(self, environ=os.environ):
+        try:
+            self.rank = int(environ["RANK"])
+            self.world_size = int(environ["WORLD_SIZE"])
+        except KeyError as e:
+            raise RuntimeError("distributed launch needs %s in the environment (start the job with "
+                               "`python -m torch.distributed.run --nproc-per-node N train.py ... --launcher pytorch`)"
+                               % e.args[0]) from e
+        # LOCAL_RANK is what torch.distributed.run exports; a launcher without it runs one node
+        self.local_rank = int(environ.get("LOCAL_RANK", self.rank))
+
+    def device(self):
+        """The GPU this rank owns (None on a CPU-only host, e.g. the gloo tests)."""
+        n = torch.cuda.device_count()
+        return torch.device("cuda", self.local_rank % n) if n > 0 and torch.cuda.is_available() else None
 
 
 def init_dist(launcher, backend="nccl", **kwargs):
-    if mp.get_start_method(allow_none=True) is None:
-        mp.set_start_method("spawn")
-    if launcher == "pytorch":
-        _init_dist_pytorch(backend, **kwargs)
-    elif launcher == "mpi":
-        raise NotImplementedError
-    elif launcher == "slurm":
-        _init_dist_slurm(backend, **kwargs)
-    else:
-        raise ValueError("Invalid launcher type: {}".format(launcher))
-
-
-def _bind_device(index):
-    n = torch.cuda.device_count()
-    if n > 0:
-        torch.cuda.set_device(index % n)
-
-
-def _init_dist_pytorch(backend, **kwargs):
-    """reference :30-35 -- RANK / WORLD_SIZE / MASTER_* come from the launcher; the device is
-    LOCAL_RANK when the launcher provides it, otherwise rank % device_count as in the reference."""
-    rank = int(os.environ["RANK"])
-    _bind_device(int(os.environ.get("LOCAL_RANK", rank)))
-    if backend == "nccl" and not torch.cuda.is_available():
-        backend = "gloo"        # CPU-only host (tests): RCCL needs a GPU
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC, required by RCCL on this driver
-    dist.init_process_group(backend=backend, **kwargs)
-
-
-def _init_dist_slurm(backend, port=29500, **kwargs):
-    proc_id = int(os.environ["SLURM_PROCID"])
-    ntasks = int(os.environ["SLURM_NTASKS"])
-    node_list = os.environ["SLURM_NODELIST"]
-    _bind_device(proc_id)
-    addr = subprocess.getoutput("scontrol show hostname {} | head -n1".format(node_list))
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ["MASTER_ADDR"] = addr
-    os.environ["WORLD_SIZE"] = str(ntasks)
-    os.environ["RANK"] = str(proc_id)
-    dist.init_process_group(backend=backend)
+    """Join the job's process group.  ``backend='nccl'`` is RCCL on ROCm; on a host without a GPU the
+    group falls back to gloo so that the same entry point serves the CPU tests."""
+    if launcher not in _LAUNCHERS:
+        raise ValueError("unsupported launcher %r: this build starts its ranks with torch.distributed.run "
+                         "(launcher='pytorch')" % (launcher,))
+    if dist.is_initialized():
+        return
+    env = RankEnv()
+    dev = env.device()
+    # the host driver only supports dmabuf IPC; RCCL's intra-node transport needs this before the first HIP call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if dev is None:
+        dist.init_process_group("gloo" if backend == "nccl" else backend, **kwargs)
+        return
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        kwargs.setdefault("device_id", dev)
+    dist.init_process_group(backend, **kwargs)
 
 
 def set_random_seed(seed):
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    """Seed python, numpy and torch (host and every visible GPU generator)."""
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
 
 
 def get_root_logger(log_level=logging.INFO):
+    """Root logger: full output on rank 0, errors only elsewhere."""
     logger = logging.getLogger()
     if not logger.hasHandlers():
         logging.basicConfig(format="%(asctime)s - %(levelname)s - %(message)s", level=log_level)
-    rank, _ = get_dist_info()
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     if rank != 0:
-        logger.setLevel("ERROR")
+        logger.setLevel(logging.ERROR)
     return logger

@@ -14,6 +14,36 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
 
+# Execution mode of the networks, set by train_mono from the config (keys this build adds; absent keys take the
+# MI355X defaults, so the reference's configs run on the fast path unchanged):
+#   amp            "bf16" (default on a HIP device) | "fp32"/None -- autocast dtype of the convolutional networks;
+#                  the loss hot path always runs in the fp32 HIP kernels
+#   channels_last  True (default on a HIP device) -- NHWC weights/activations: the layout the hand-written
+#                  BatchNorm / pool / pad / join kernels and MIOpen's MFMA implicit-GEMM kernels take
+#   strict_dispatch  False -- raise instead of warn when a HIP tensor falls back to an ATen composition
+_MODE = {"autocast": None}
+
+
+def configure_execution(model, cfg, dev):
+    """Apply cfg.amp / cfg.channels_last / cfg.strict_dispatch to ``model`` (before it is wrapped and before the
+    optimizer is built) and to batch_processor's autocast.  Returns the model."""
+    on_gpu = dev.type == "cuda"
+    amp = cfg.get("amp", "bf16" if on_gpu else None)
+    if amp in (None, False, "fp32", "none"):
+        _MODE["autocast"] = None
+    elif amp == "bf16":
+        _MODE["autocast"] = torch.bfloat16
+    else:
+        raise ValueError("cfg.amp must be 'bf16' or 'fp32', got %r" % (amp,))
+    model = model.to(dev)
+    if cfg.get("channels_last", on_gpu):
+        model = model.to(memory_format=torch.channels_last)
+    if on_gpu:
+        from tripled_amd import dispatch
+        dispatch.set_strict(bool(cfg.get("strict_dispatch", False)))
+    return model
+
+
 def change_input_variable(data):
     """reference :19-29: every entry of the batch dict -> float32 on the training device.  The
     copies are issued non-blocking (they are asynchronous when the loader pins memory)."""
@@ -34,7 +64,10 @@ def batch_processor(model, data, train_mode):
     if train_mode:
         model.train()
     data = change_input_variable(data)
-    model_out, losses = model(data)
+    dtype = _MODE["autocast"]
+    on_gpu = next(iter(data.values())).is_cuda if isinstance(data, dict) else False
+    with torch.autocast("cuda" if on_gpu else "cpu", dtype=dtype, enabled=dtype is not None and on_gpu):
+        model_out, losses = model(data)
     log_vars = OrderedDict()
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
@@ -116,7 +149,8 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
     if cfg.get("syncbn", False):
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     dev = _device()
-    model = MMDistributedDataParallel(model.to(dev), find_unused_parameters=cfg.get("find_unused_parameters", False),
+    model = configure_execution(model, cfg, dev)
+    model = MMDistributedDataParallel(model, find_unused_parameters=cfg.get("find_unused_parameters", False),
                                       device_ids=[dev.index] if dev.type == "cuda" else None,
                                       broadcast_buffers=False)
     optimizer = build_optimizer(model, cfg.optimizer)
@@ -133,7 +167,7 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
 
 def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False):
     data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, len(cfg.gpus), dist=False)]
-    model = MMDataParallel(model, device_ids=list(range(len(cfg.gpus)))).to(_device())
+    model = MMDataParallel(configure_execution(model, cfg, _device()), device_ids=list(range(len(cfg.gpus))))
     optimizer = build_optimizer(model, cfg.optimizer)
     runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
     runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.checkpoint_config, cfg.log_config)
