@@ -313,6 +313,49 @@ int td_featwarp_bwd(const void* tgt, const void* const* src, int n_src, int dtyp
 int td_reduce_partials(const float* partial, int n_src, int B, int blocks_per_sample, float* dP,
                        td_stream_t stream);
 
+/*
+ * Robust-L1 channel-mean map between a network output and an image, and its adjoint:
+ *   out[b,y,x] = weight * mean_c sqrt((pred[b,c,y,x] - target[b,c,y,x])^2 + 1e-6)
+ * Replaces compute_perceptional_loss on images -- compute_auto_res_loss,
+ * mono/model/mono_fm_joint_inpaint/net.py:520-527 (a per-pixel MAP that batch_processor's mean reduces), and
+ * compute_colorization_loss, :310-323 -- with robust_l1 of mono/model/mono_fm_joint/net.py:59-65.
+ *   pred          C-channel tensor of dtype TD_DTYPE_F32 / TD_DTYPE_BF16 with arbitrary element strides
+ *   pred_strides  HOST array of 4 element strides (n, c, h, w): channels-last decoder outputs and channel
+ *                 slices are read in place, no .float()/.contiguous() copy
+ *   target        [B,C,H,W] fp32 NCHW;  out [B,1,H,W] fp32
+ * td_l1map_bwd: dpred (same dtype and strides as pred) = gmap[b,y,x] * weight / C * (pred - target) / sqrt(...).
+ */
+int td_l1map_fwd(const void* pred, int dtype, const long long* pred_strides, const float* target, int B, int C,
+                 int H, int W, float weight, float* out, td_stream_t stream);
+int td_l1map_bwd(const void* pred, int dtype, const long long* pred_strides, const float* target,
+                 const float* gmap, int B, int C, int H, int W, float weight, void* dpred, td_stream_t stream);
+
+/*
+ * sRGB -> normalised CIE Lab: rgb2lab, mono/model/mono_fm_joint_inpaint/color_conversions.py:106-114 (rgb2xyz
+ * :6-27, xyz2lab :52-75), called on the target frame by the colourisation models (net.py:236,292).
+ *   rgb [B,3,H,W] fp32 in [0,1];  lab [B,3,H,W] = ((L - l_cent) / l_norm, a / ab_norm, b / ab_norm).
+ * No gradient (the input is data).
+ */
+int td_rgb2lab(const float* rgb, int B, int H, int W, float l_cent, float l_norm, float ab_norm, float* lab,
+               td_stream_t stream);
+
+/*
+ * Pose vectors -> camera transforms -> projection matrices for all frame pairs of a step in one launch.
+ * Replaces transformation_from_parameters / rot_from_axisangle / get_translation_matrix,
+ * mono/model/mono_fm_joint/net.py:225-277, and torch.matmul(K, T)[:, :3, :] of Project.forward,
+ * mono/model/mono_fm_joint/layers.py:73-75.
+ *   axisangle, translation  [n_pairs*B, 3] (PoseDecoder outputs, pair-major)
+ *   invert                  HOST array of n_pairs flags (frame id < 0: M = R^T Trans(-t), else Trans(t) R)
+ *   K                       [B,4,4] intrinsics (may be NULL when P is NULL)
+ *   T   [n_pairs,B,4,4] (out)     P  [n_pairs,B,3,4] = (K @ T)[:, :3, :] (out, may be NULL)
+ * td_pose_bwd: g_axisangle / g_translation [n_pairs*B,3] from gT and/or gP (either may be NULL, not both).
+ */
+int td_pose_fwd(const float* axisangle, const float* translation, const int* invert, const float* K,
+                int n_pairs, int B, float* T, float* P, td_stream_t stream);
+int td_pose_bwd(const float* axisangle, const float* translation, const int* invert, const float* K,
+                int n_pairs, int B, const float* gT, const float* gP, float* g_axisangle,
+                float* g_translation, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

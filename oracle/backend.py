@@ -18,7 +18,8 @@ class OracleLossBackend:
         c.opt, c.target, c.sources, c.K, c.inv_K = opt, target, list(sources), K, inv_K
         return c
 
-    def photometric(self, ctx, disp, Ts, noise, keep_warped=False):
+    def photometric(self, ctx, disp, Ts, noise, keep_warped=False, P=None):
+        # P (the product's pre-multiplied K @ T) is ignored: the oracle follows the reference and forms it from Ts
         opt = ctx.opt
         draws = None
         if noise is not None:

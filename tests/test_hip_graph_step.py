@@ -17,10 +17,11 @@ Two comparisons, tolerances stated:
    |delta| <= 0.25 * lr (measured 0.03-0.06 lr).  The same bounds are asserted eager-vs-eager (noise floor:
    measured values are the same as graph-vs-eager, tools/diag_capture.py and gpurun logs of round 2).
 2. FREE-RUNNING (loose).  K consecutive replays against K consecutive eager steps: the atomics noise is
-   amplified by the sign-like Adam updates through ~100 bf16 layers, so the trajectories separate at the
-   bf16-ulp level (ulp = 2^-8 near disp = 1).  Asserted at every step: every loss entry within 2e-3 + 2 %, total
-   within 2e-3, mean |disp difference| < 2 ulp at every scale.  The same bound is asserted between two EAGER
-   runs (the noise floor), so the tolerance is the path's own run-to-run spread, not slack for the graph.
+   amplified by the sign-like Adam updates through ~100 bf16 layers, so the trajectories separate chaotically
+   (two EAGER runs from the same state were measured 1 to 3 bf16 ulp apart in mean disparity after ONE update,
+   run-dependent).  This part is therefore a sanity check on the loss trajectory only: every loss entry within
+   2e-3 + 2 %, total within 2e-3, mean |disp difference| < 0.05 at every scale, asserted for graph-vs-eager and
+   for eager-vs-eager alike.  The parity statement proper is comparison 1.
 
 Plus: zero ATen fallbacks (strict mode), all parameters finite after 25 further replays.
 """
@@ -89,7 +90,7 @@ def _compare_loose(tag, ref, got):
         for k in l_r:
             assert abs(l_r[k] - l_g[k]) < 2e-3 + 2e-2 * abs(l_r[k]), (tag, i, k, l_r[k], l_g[k])
         for s, (a, b) in enumerate(zip(d_r, d_g)):
-            assert float((a - b).abs().mean()) < 2 * ULP, (tag, i, s, float((a - b).abs().mean()))
+            assert float((a - b).abs().mean()) < 0.05, (tag, i, s, float((a - b).abs().mean()))
 
 
 def _compare_tight(tag, i, ref, got):

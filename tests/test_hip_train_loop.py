@@ -35,12 +35,22 @@ def test_train_mono_one_epoch(tmp_path):
         lr_config=dict(policy="step", warmup="linear", warmup_iters=3, warmup_ratio=1.0 / 3, step=[10, 20], gamma=0.5),
         checkpoint_config=dict(interval=1), log_config=dict(interval=2, hooks=[dict(type="TextLoggerHook")]),
         dist_params=dict(backend="nccl"), log_level="INFO", workflow=[("train", 1)], syncbn=False,
-        work_dir=str(tmp_path), gpus=[0]))
+        work_dir=str(tmp_path), gpus=[0],
+        # the execution mode of the benchmark, reached through train_mono (mono/apis/trainer.py::configure_execution);
+        # strict: any HIP tensor that would fall back to an ATen composition raises
+        amp="bf16", channels_last=True, strict_dispatch=True))
+    from tripled_amd import dispatch
+    dispatch.reset()
     torch.manual_seed(0)
     model = MONO.module_dict[cfg.model["name"]](cfg.model)
     before = model.DepthDecoder.disp1[0].conv.weight.detach().clone()
     train_mono(model, get_dataset(cfg.data, training=True), get_dataset(cfg.data, training=False), cfg,
                distributed=False, validate=True)
+    dispatch.set_strict(False)
+    assert sum(dispatch.fallbacks.values()) == 0, dict(dispatch.fallbacks)
+    assert dispatch.hip_calls["td_bn_fwd"] > 0 and dispatch.hip_calls["td_maxpool5_fwd"] > 0      # the fast path ran
+    assert next(model.parameters()).is_cuda and model.DepthEncoder.encoder.layer1[0].conv1.weight.is_contiguous(
+        memory_format=torch.channels_last)
     assert os.path.exists(tmp_path / "epoch_1.pth")
     ckpt = torch.load(tmp_path / "epoch_1.pth", weights_only=False)
     assert ckpt["meta"]["iter"] == 4 and "DepthDecoder.disp1.0.conv.weight" in ckpt["state_dict"]

@@ -54,6 +54,17 @@ def test_ops_pose(golden_dir):
     close(eye, np.tile(np.eye(4, dtype=np.float32), (3, 1, 1)), atol=0)
 
 
+def test_color_lab_and_l1_map(golden_dir):
+    from oracle import color
+    z = load(golden_dir, "color_lab.npz")
+    close(color.rgb2lab(T(z["rgb"])), z["lab"], atol=2e-6)
+    pred = T(z["pred"]).requires_grad_(True)
+    m = color.robust_l1_map(pred, T(z["rgb"]), 5e-3)
+    close(m, z["l1map"], atol=1e-9)
+    m.mean().backward()
+    close(pred.grad, z["d_pred"], atol=1e-10)
+
+
 def test_ops_ssim_and_smooth(golden_dir):
     z = load(golden_dir, "ops_small.npz")
     close(photometric.ssim_loss(T(z["ssim_x"]), T(z["ssim_y"])), z["ssim"], atol=1e-6)

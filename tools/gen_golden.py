@@ -402,6 +402,24 @@ def gen_metrics(ref):
     save("metrics.npz", gt=gt, pred=pred, errors=errs, errors_same=same, disp=disp, scaled_disp=sd, depth=dp)
 
 
+def gen_color():
+    """rgb2lab of the colourisation models (mono/model/mono_fm_joint_inpaint/color_conversions.py:106-114) and the
+    robust-L1 channel-mean map of compute_auto_res_loss (net.py:520-527) on small images."""
+    import argparse as _ap
+    cc = importlib.import_module("mono.model.mono_fm_joint_inpaint.color_conversions")
+    g = torch.Generator().manual_seed(21)
+    rgb = smooth_image(g, 2, 3, 24, 40)
+    rgb[0, :, :2, :3] = 0.0                      # exercise both branches of the gamma / cube-root thresholds
+    rgb[1, :, -2:, -3:] = 1.0
+    rgb[0, :, 5, 5] = 0.03
+    lab = cc.rgb2lab(rgb, _ap.Namespace(l_cent=50.0, l_norm=50.0, ab_norm=110.0))
+    pred = smooth_image(g, 2, 3, 24, 40).requires_grad_(True)
+    eps = 1e-3
+    l1map = torch.sqrt(torch.pow(pred - rgb, 2) + eps ** 2).mean(1, True) * 5e-3      # net.py:59-65, :520-527
+    l1map.mean().backward()
+    save("color_lab.npz", rgb=npy(rgb), lab=npy(lab), pred=npy(pred), l1map=npy(l1map), d_pred=npy(pred.grad))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -417,6 +435,7 @@ def main():
     gen_losses_tripled(ref_inpaint)
     gen_losses_fm(ref_fm)
     gen_metrics(args.ref)
+    gen_color()
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ import torch
 
 
 class StepContext:
-    __slots__ = ("opt", "target", "sources", "K", "inv_K", "idloss", "pyramid")
+    __slots__ = ("opt", "target", "sources", "K", "inv_K", "idloss", "pyramid", "P_cache")
 
 
 class HipLossBackend:
@@ -35,6 +35,7 @@ class HipLossBackend:
         ctx.opt, ctx.target, ctx.sources, ctx.K, ctx.inv_K = opt, target, list(sources), K, inv_K
         ctx.idloss = self.ops.photo_identity(target, ctx.sources) if opt.automask else None
         ctx.pyramid = {}
+        ctx.P_cache = None
         return ctx
 
     def image_at(self, ctx, h, w):
@@ -43,9 +44,15 @@ class HipLossBackend:
             ctx.pyramid[key] = self.ops.area_downsample(ctx.target, h, w)
         return ctx.pyramid[key]
 
-    def photometric(self, ctx, disp, Ts, noise, keep_warped=False):
+    def photometric(self, ctx, disp, Ts, noise, keep_warped=False, P=None):
+        """``P`` [n_src,B,3,4] = (K @ T)[:, :3, :] when the caller already holds it (ops.pose_transforms emits it
+        with the transforms); otherwise it is formed from ``Ts`` once per step, not once per scale."""
         opt = ctx.opt
-        P = torch.stack([torch.matmul(ctx.K, T)[:, :3, :] for T in Ts], 0)
+        if P is None:
+            key = tuple(id(T) for T in Ts)
+            if ctx.P_cache is None or ctx.P_cache[0] != key:
+                ctx.P_cache = (key, torch.stack([torch.matmul(ctx.K, T)[:, :3, :] for T in Ts], 0))
+            P = ctx.P_cache[1]
         loss, argmin, warped = self.ops.photometric_scale_loss(
             disp, P, ctx.target, ctx.sources, ctx.inv_K, ctx.idloss, noise,
             opt.min_depth, opt.max_depth, len(opt.scales), keep_warped)

@@ -71,12 +71,26 @@ class mono_fm(mono_fm_joint):
         ctx = self._begin_step(inputs)
         for scale in opt.scales:
             self._photometric_scale(ctx, inputs, outputs, scale, loss_dict)
-            outputs = self.generate_features_pred(inputs, outputs)
-            cands = []
-            for f in opt.frame_ids[1:]:
-                tgt_f = self._target_features(inputs[("color", 0, 0)]).float()
-                cands.append(self.compute_perceptional_loss(tgt_f, outputs[("feature", f, 0)]))
-            vals, outputs[("min_index", scale)] = torch.min(torch.cat(cands, 1), dim=1)
-            loss_dict[("min_perceptional_loss", scale)] = opt.perception_weight * vals.mean() / n_scales
+            fused = None
+            if self._fused_features_possible(inputs, self.extractor):
+                def target_features():
+                    # the reference evaluates the extractor on the target once per source frame (:113), after the
+                    # source frames (:198 inside generate_features_pred); the passes are kept (they advance the
+                    # BatchNorm running statistics) and the last one feeds the fused warp + min kernel
+                    for _ in opt.frame_ids[1:]:
+                        f = self._target_features(inputs[("color", 0, 0)])
+                    return f
+                fused = self._fused_feature_metric(inputs, outputs, target_features)
+            if fused is not None:
+                loss, outputs[("min_index", scale)] = fused
+                loss_dict[("min_perceptional_loss", scale)] = opt.perception_weight * loss / n_scales
+            else:
+                outputs = self.generate_features_pred(inputs, outputs)
+                cands = []
+                for f in opt.frame_ids[1:]:
+                    tgt_f = self._target_features(inputs[("color", 0, 0)]).float()
+                    cands.append(self.compute_perceptional_loss(tgt_f, outputs[("feature", f, 0)]))
+                vals, outputs[("min_index", scale)] = torch.min(torch.cat(cands, 1), dim=1)
+                loss_dict[("min_perceptional_loss", scale)] = opt.perception_weight * vals.mean() / n_scales
             self._smooth_scale(ctx, outputs, scale, loss_dict)
         return loss_dict

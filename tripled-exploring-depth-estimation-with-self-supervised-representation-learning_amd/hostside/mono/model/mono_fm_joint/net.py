@@ -122,7 +122,8 @@ class mono_fm_joint(nn.Module):
             noise = self._automask_noise(len(ctx.sources), (b, h, w), target.device)
         keep = bool(opt.get("keep_warped_images", False))
         loss, min_index, warped = self.loss_backend.photometric(
-            ctx, outputs[("disp", 0, scale)].float(), self._frame_transforms(inputs, outputs), noise, keep)
+            ctx, outputs[("disp", 0, scale)].float(), self._frame_transforms(inputs, outputs), noise, keep,
+            P=outputs.get(("cam_P", 0)))
         if warped is not None:
             for f, wimg in zip(opt.frame_ids[1:], warped):
                 outputs[("color", f, scale)] = wimg
@@ -187,6 +188,53 @@ class mono_fm_joint(nn.Module):
             return self.Encoder.stem_only(img)
         return self.Encoder(img)[0]
 
+    def _fused_features_possible(self, inputs, extractor):
+        """Decided BEFORE any extractor pass runs (a declined fused path must not leave extra BatchNorm
+        running-statistics updates behind): HIP inputs, nobody asked for the warped feature maps, no stereo
+        frame, and the extractor produces channels-last activations."""
+        opt = self.opt
+        if not inputs[("color", 0, 0)].is_cuda or opt.get("keep_warped_images", False) or "s" in opt.frame_ids:
+            return False
+        if not extractor.encoder.conv1.weight.is_contiguous(memory_format=torch.channels_last):
+            from tripled_amd import dispatch
+            dispatch.fallback("feature_metric_warp", "the extractor is not in channels_last memory format")
+            return False
+        return True
+
+    def _fused_feature_metric(self, inputs, outputs, tgt_f):
+        """Feature-metric term through the fused HIP kernel (no warped feature maps are materialised).
+        ``tgt_f``: the target features, or a callable that produces them AFTER the source-frame passes (the
+        reference's order in mono_fm, which fixes the order of the BatchNorm running-statistics updates).
+        None when the feature layout is not one the kernel takes (reported as a fallback)."""
+        opt = self.opt
+        from tripled_amd import ops
+        imgs = [inputs[("color", f, 0)] for f in opt.frame_ids[1:]]
+        if self._batch_frames(imgs):
+            # both source frames through the extractor in one stacked pass (per-pass BatchNorm statistics)
+            with bn_groups(len(imgs)):
+                stacked = self._source_features(torch.cat(imgs, 0))
+            src_f = list(stacked.split(imgs[0].shape[0], 0))      # split: its backward is one cat, not zero-filled slices
+        else:
+            src_f = [self._source_features(img) for img in imgs]
+        if callable(tgt_f):
+            tgt_f = tgt_f()
+        if not ops.featwarp_supported(tgt_f, src_f):
+            from tripled_amd import dispatch
+            dispatch.fallback("feature_metric_warp", "dtype %s, shape %s" % (tgt_f.dtype, tuple(tgt_f.shape)))
+            return None
+        inv_K = inputs["inv_K"].float().clone()
+        inv_K[:, :, 0:2] = inv_K[:, :, 0:2] * 2          # see generate_features_pred
+        P_full = outputs.get(("cam_P", 0))
+        if P_full is not None:
+            # K' = diag(.5, .5, 1, 1) K  =>  (K' T)[:3] is (K T)[:3] with rows 0 and 1 halved (exact: powers of two)
+            P = torch.cat([P_full[:, :, :2] * 0.5, P_full[:, :, 2:]], 2)
+        else:
+            K = inputs["K"].float().clone()
+            K[:, 0:2, :] = K[:, 0:2, :] / 2
+            P = torch.stack([torch.matmul(K, outputs[("cam_T_cam", 0, f)].float())[:, :3, :] for f in opt.frame_ids[1:]], 0)
+        return ops.feature_warp_min_loss(tgt_f, src_f, outputs[("disp", 0, 0)].float(), P, inv_K,
+                                         opt.min_depth, opt.max_depth)
+
     def generate_features_pred(self, inputs, outputs):
         """net.py:196-223: warp the extractor's stem features of each source frame to the target
         view at half resolution (K rows 0,1 halved, inv_K re-derived)."""
@@ -236,8 +284,21 @@ class mono_fm_joint(nn.Module):
                 axisangle, translation = self.PoseDecoder(self.PoseEncoder(torch.cat(pairs, 0)))
             n = pairs[0].shape[0]
             per_pair = list(zip(axisangle.split(n, 0), translation.split(n, 0)))
+            stacked = (axisangle, translation)
         else:
             per_pair = [self.PoseDecoder(self.PoseEncoder(x)) for x in pairs]
+            stacked = None
+        if pairs and pairs[0].is_cuda:
+            # one HIP launch for every pair: Rodrigues + translation + K @ T (tripled_amd.ops.pose_transforms)
+            from tripled_amd import ops
+            if stacked is None:
+                stacked = (torch.cat([a for a, _ in per_pair], 0), torch.cat([t for _, t in per_pair], 0))
+            T, P = ops.pose_transforms(stacked[0], stacked[1], inputs["K"].float(), [f < 0 for f in frames])
+            for i, f in enumerate(frames):
+                outputs[("cam_T_cam", 0, f)] = T[i]
+            if len(frames) == len(self.opt.frame_ids) - 1:        # no stereo frame: P covers every source frame
+                outputs[("cam_P", 0)] = P
+            return outputs
         for f, (axisangle, translation) in zip(frames, per_pair):
             outputs[("cam_T_cam", 0, f)] = self.transformation_from_parameters(
                 axisangle[:, 0], translation[:, 0], invert=(f < 0))

@@ -49,32 +49,15 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             return outputs, self.compute_losses(inputs, outputs, features)
         return outputs
 
-    def _fused_feature_metric(self, inputs, outputs, tgt_f):
-        """Feature-metric term through the fused HIP kernel (no warped feature maps are materialised);
-        None when the inputs are not channels-last HIP tensors or the caller wants the warped features."""
-        opt = self.opt
-        if not tgt_f.is_cuda or opt.get("keep_warped_images", False) or "s" in opt.frame_ids:
-            return None
-        from tripled_amd import ops
-        imgs = [inputs[("color", f, 0)] for f in opt.frame_ids[1:]]
-        if self._batch_frames(imgs):
-            # both source frames through the extractor in one stacked pass (per-pass BatchNorm statistics)
-            with bn_groups(len(imgs)):
-                stacked = self._source_features(torch.cat(imgs, 0))
-            src_f = list(stacked.split(imgs[0].shape[0], 0))      # split: its backward is one cat, not zero-filled slices
-        else:
-            src_f = [self._source_features(img) for img in imgs]
-        if not ops.featwarp_supported(tgt_f, src_f):
-            from tripled_amd import dispatch
-            dispatch.fallback("feature_metric_warp", "dtype %s, shape %s" % (tgt_f.dtype, tuple(tgt_f.shape)))
-            return None
-        K = inputs["K"].float().clone()
-        K[:, 0:2, :] = K[:, 0:2, :] / 2
-        inv_K = inputs["inv_K"].float().clone()
-        inv_K[:, :, 0:2] = inv_K[:, :, 0:2] * 2          # see generate_features_pred
-        P = torch.stack([torch.matmul(K, outputs[("cam_T_cam", 0, f)].float())[:, :3, :] for f in opt.frame_ids[1:]], 0)
-        return ops.feature_warp_min_loss(tgt_f, src_f, outputs[("disp", 0, 0)].float(), P, inv_K,
-                                         opt.min_depth, opt.max_depth)
+    def _image_l1_map(self, pred, target, weight):
+        """weight * compute_perceptional_loss(target, pred) as a [B,1,H,W] map: one HIP pass over the decoder output
+        in its own dtype/layout on the GPU (tripled_amd.ops.robust_l1_map), the reference's ops on the CPU."""
+        if pred.is_cuda:
+            from tripled_amd import dispatch, ops
+            if ops.robust_l1_map_supported(pred, target):
+                return ops.robust_l1_map(pred, target, weight)
+            dispatch.fallback("image_l1_map", "dtype %s, shape %s, strides %s" % (pred.dtype, tuple(pred.shape), pred.stride()))
+        return self.compute_perceptional_loss(target, pred.float()) * weight
 
     def _masked_reconstruction(self, inputs, outputs, scale):
         """reference :80-91: photometric loss of the auto-encoder output against the resized target,
@@ -106,7 +89,8 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             for i in range(5):
                 loss_dict[("feature_regularization_loss", i)] = \
                     self.get_feature_regularization_loss(features[i], target) / (2 ** i) / 5
-            fused = self._fused_feature_metric(inputs, outputs, features[0])
+            fused = self._fused_feature_metric(inputs, outputs, features[0]) \
+                if self._fused_features_possible(inputs, self.Encoder) else None
             if fused is not None:
                 loss, outputs["min_index"] = fused
                 loss_dict["min_perceptional_loss"] = opt.perception_weight * loss
@@ -218,8 +202,8 @@ class mono_fm_joint_inpaint_disentangle(mono_fm_joint_inpaint):
         """reference :520-527 -- note: a per-pixel MAP, reduced later by batch_processor's mean."""
         if not self.opt.auto_res_weight > 0.0:
             return {}
-        loss = self.compute_perceptional_loss(inputs[("color", 0, 0)], outputs[("auto_res_img", 0, 0)].float())
-        return {"auto_res_loss": loss * self.opt.auto_res_weight}
+        return {"auto_res_loss": self._image_l1_map(outputs[("auto_res_img", 0, 0)], inputs[("color", 0, 0)],
+                                                    self.opt.auto_res_weight)}
 
     def compute_losses(self, inputs, outputs, features):
         loss_dict = super().compute_losses(inputs, outputs, features)
@@ -253,7 +237,12 @@ class mono_fm_joint_inpaint_disentangle_distill_sep_colorize(mono_fm_joint_inpai
         if not self.training:
             return outputs
         outputs.update(self.predict_poses(inputs))
-        lab = self.to_lab(inputs[("color", 0, 0)], argparse.Namespace(l_cent=50.0, l_norm=50.0, ab_norm=110.0))
+        img = inputs[("color", 0, 0)]
+        if img.is_cuda:
+            from tripled_amd import ops
+            lab = ops.rgb2lab(img, 50.0, 50.0, 110.0)      # one HIP pass (color_conversions.py: ~25 element-wise launches)
+        else:
+            lab = self.to_lab(img, argparse.Namespace(l_cent=50.0, l_norm=50.0, ab_norm=110.0))
         grey = lab[:, 0:1].expand(-1, 3, -1, -1)
         grey_emb = self.ColorizeEncoder(grey, depth_emb if opt.get("cond_encoder", False) else None)
         outputs = self.ColorizeDecoder(grey_emb, outputs)
@@ -266,7 +255,7 @@ class mono_fm_joint_inpaint_disentangle_distill_sep_colorize(mono_fm_joint_inpai
         opt = self.opt
         if not opt.colorize_weight > 0.0:
             return {}
-        loss = self.compute_perceptional_loss(inputs["gt_ab"], outputs[("auto_res_img", 0, 0)].float())
+        loss = self._image_l1_map(outputs[("auto_res_img", 0, 0)], inputs["gt_ab"], 1.0)
         if opt.get("use_distill_mask", False):
             hole = 1 - inputs[("mask", 0, 0)][:, 0:1]
             loss = torch.sum(loss * hole) / torch.sum(hole)

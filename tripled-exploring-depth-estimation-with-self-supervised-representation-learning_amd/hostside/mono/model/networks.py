@@ -38,8 +38,10 @@ def _dense_cl(x):
 
 def _fell_back(site, x, why=""):
     """An activation that lives on a HIP device takes an ATen composition instead of the hand-written kernel
-    (tripled_amd.dispatch: counted; raises in strict mode).  CPU tensors are not reported."""
-    if x.is_cuda:
+    (tripled_amd.dispatch: counted; raises in strict mode).  The accounting covers the training step: CPU tensors
+    and no-grad passes (the fp32 evaluation forward of the validation hooks, which keeps the reference's
+    precision and feeds 513-channel fp32 concatenations the 8-channel-vector kernels do not take) are not reported."""
+    if x.is_cuda and torch.is_grad_enabled():
         from tripled_amd import dispatch
         dispatch.fallback(site, why or "dtype %s, shape %s, channels_last %s" % (
             x.dtype, tuple(x.shape), x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)))

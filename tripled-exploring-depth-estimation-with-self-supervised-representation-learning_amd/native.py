@@ -20,6 +20,8 @@ _c_u8_p = ctypes.c_void_p
 # name -> (restype, argtypes); mirrors include/tripled_hip.h one to one
 _PTRARR = ctypes.POINTER(ctypes.c_void_p)
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_LLARR = ctypes.POINTER(ctypes.c_longlong)     # host arrays
+_IARR = ctypes.POINTER(ctypes.c_int)
 SIGNATURES = {
     "td_abi_version": (_I, []),
     "td_error_string": (ctypes.c_char_p, [_I]),
@@ -62,6 +64,11 @@ SIGNATURES = {
     "td_featwarp_bwd": (_I, [_P, _PTRARR, _I, _I, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _P, _PTRARR,
                              _P, _P, _P]),
     "td_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),
+    "td_l1map_fwd": (_I, [_P, _I, _LLARR, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "td_l1map_bwd": (_I, [_P, _I, _LLARR, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "td_rgb2lab": (_I, [_P, _I, _I, _I, _F, _F, _F, _P, _P]),
+    "td_pose_fwd": (_I, [_P, _P, _IARR, _P, _I, _I, _P, _P, _P]),
+    "td_pose_bwd": (_I, [_P, _P, _IARR, _P, _I, _I, _P, _P, _P, _P, _P]),
 }
 
 DTYPE_CODES = {torch.float32: 0, torch.bfloat16: 1}
@@ -130,3 +137,12 @@ def ptr_array(tensors):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def strides_array(t):
+    """Element strides of a 4-D tensor as a host long-long array."""
+    return (ctypes.c_longlong * 4)(*[int(v) for v in t.stride()])
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])

@@ -586,3 +586,93 @@ def feature_warp_min_loss(tgt_f, src_f, disp, P, invK, min_depth, max_depth):
     mono_fm_joint_inpaint/net.py:58-70).  P / invK are at the feature resolution.
     Returns (loss, argmin uint8 [B,h,w])."""
     return _FeatureWarpLoss.apply(tgt_f, disp, P, _f32c(invK), min_depth, max_depth, *src_f)
+
+
+class _RobustL1Map(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        lib = native.load()
+        B, C, H, W = pred.shape
+        out = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
+        native.check(lib.td_l1map_fwd(_raw(pred), native.DTYPE_CODES[pred.dtype], native.strides_array(pred), native.ptr(target),
+                                      B, C, H, W, float(weight), native.ptr(out), native.stream()), "td_l1map_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.weight = float(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        pred, target = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        g = _f32c(g)                                         # (an expanded mean-gradient becomes a dense map here)
+        dpred = torch.empty_strided(pred.size(), pred.stride(), device=pred.device, dtype=pred.dtype)
+        native.check(lib.td_l1map_bwd(_raw(pred), native.DTYPE_CODES[pred.dtype], native.strides_array(pred), native.ptr(target),
+                                      native.ptr(g), B, C, H, W, ctx.weight, _raw(dpred), native.stream()), "td_l1map_bwd")
+        return dpred, None, None
+
+
+def robust_l1_map_supported(pred, target):
+    return (pred.is_cuda and pred.dim() == 4 and pred.dtype in native.DTYPE_CODES and target.shape == pred.shape
+            and pred.shape[1] <= 64 and torch.ops.aten.is_non_overlapping_and_dense(pred))
+
+
+def robust_l1_map(pred, target, weight=1.0):
+    """weight * mean_c sqrt((pred - target)^2 + 1e-6) -> [B,1,H,W]: compute_perceptional_loss between a decoder
+    output (any dense layout, f32/bf16, read in place) and an image (reference: compute_auto_res_loss,
+    mono_fm_joint_inpaint/net.py:520-527; compute_colorization_loss, :310-323).  Gradient to ``pred`` only."""
+    if not robust_l1_map_supported(pred, target):
+        raise native.NativeLibraryError("robust_l1_map needs a dense f32/bf16 HIP prediction and a same-shape target")
+    return _RobustL1Map.apply(pred, _f32c(target.detach()), weight)
+
+
+def rgb2lab(rgb, l_cent=50.0, l_norm=50.0, ab_norm=110.0):
+    """Normalised Lab of an sRGB image batch [B,3,H,W] (reference: color_conversions.py:106-114); no gradient."""
+    lib = native.load()
+    rgb = _f32c(rgb.detach())
+    B, C, H, W = rgb.shape
+    if C != 3:
+        raise ValueError("rgb2lab expects 3 channels")
+    lab = torch.empty_like(rgb)
+    native.check(lib.td_rgb2lab(native.ptr(rgb), B, H, W, float(l_cent), float(l_norm), float(ab_norm), native.ptr(lab),
+                                native.stream()), "td_rgb2lab")
+    return lab
+
+
+class _PoseTransforms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, K, invert):
+        lib = native.load()
+        n = len(invert)
+        B = axisangle.shape[0] // n
+        T = torch.empty(n, B, 4, 4, device=axisangle.device, dtype=torch.float32)
+        P = torch.empty(n, B, 3, 4, device=axisangle.device, dtype=torch.float32)
+        native.check(lib.td_pose_fwd(native.ptr(axisangle), native.ptr(translation), native.int_array(invert), native.ptr(K), n, B,
+                                     native.ptr(T), native.ptr(P), native.stream()), "td_pose_fwd")
+        ctx.save_for_backward(axisangle, translation, K)
+        ctx.invert = tuple(invert)
+        return T, P
+
+    @staticmethod
+    def backward(ctx, gT, gP):
+        lib = native.load()
+        axisangle, translation, K = ctx.saved_tensors
+        n = len(ctx.invert)
+        B = axisangle.shape[0] // n
+        ga, gt = torch.empty_like(axisangle), torch.empty_like(translation)
+        native.check(lib.td_pose_bwd(native.ptr(axisangle), native.ptr(translation), native.int_array(ctx.invert), native.ptr(K), n, B,
+                                     native.ptr(_f32c(gT)) if gT is not None else None,
+                                     native.ptr(_f32c(gP)) if gP is not None else None,
+                                     native.ptr(ga), native.ptr(gt), native.stream()), "td_pose_bwd")
+        return ga, gt, None, None
+
+
+def pose_transforms(axisangle, translation, K, invert):
+    """All frame pairs of a step at once: (T [n,B,4,4], P [n,B,3,4] = (K @ T)[:, :3, :]) from the PoseDecoder's
+    pair-major outputs axisangle / translation [n*B,3] (reference: transformation_from_parameters,
+    mono_fm_joint/net.py:225-277; Project.forward's K @ T, layers.py:73-75).  ``invert[i]``: frame id < 0."""
+    a = _f32c(axisangle.reshape(-1, 3))
+    t = _f32c(translation.reshape(-1, 3))
+    if a.shape[0] % len(invert):
+        raise ValueError("pose rows %d are not %d pairs of equal batch" % (a.shape[0], len(invert)))
+    return _PoseTransforms.apply(a, t, _f32c(K), [bool(v) for v in invert])
