@@ -7,7 +7,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (1, 256, 12, 40), (3, 8, 1, 5), (2, 64, 24, 80)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (1, 256, 12, 40), (3, 8, 1, 5), (2, 64, 24, 80),
+                                     (12, 256, 48, 160), (4, 256, 80, 256)])             # C2 / C4 stage-1 CRP block
 def test_maxpool5_matches_aten(dtype, N, C, H, W):
     import tripled_amd  # noqa: F401
     from tripled_amd import ops

@@ -8,7 +8,8 @@ from oracle import photometric  # noqa: E402
 from tests.util import rel_err, smooth_image  # noqa: E402
 
 
-@pytest.mark.parametrize("B,h,w", [(2, 24, 80), (1, 3, 3), (2, 17, 131), (1, 48, 60), (3, 9, 62), (1, 8, 124)])
+@pytest.mark.parametrize("B,h,w", [(2, 24, 80), (1, 3, 3), (2, 17, 131), (1, 48, 60), (3, 9, 62), (1, 8, 124),
+                                   (12, 192, 640), (12, 24, 80), (4, 320, 1024)])      # C2 scale 0 / 3, C4 scale 0
 def test_masked_reconstruction(B, h, w):
     import tripled_amd  # noqa: F401
     from tripled_amd import ops

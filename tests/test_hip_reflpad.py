@@ -7,7 +7,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N,C,H,W", [(2, 16, 6, 20), (1, 256, 3, 3), (2, 8, 2, 5), (1, 64, 12, 40)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 6, 20), (1, 256, 3, 3), (2, 8, 2, 5), (1, 64, 12, 40),
+                                     (12, 520, 48, 160), (12, 16, 192, 640)])            # C2: widest decoder pad, image-decoder head
 def test_reflpad1(dtype, N, C, H, W):
     import tripled_amd  # noqa: F401
     from tripled_amd import ops

@@ -62,3 +62,19 @@ def assert_argmin_parity(argmin, ref_idx, stack, tol=2e-5, max_frac=5e-3):
             int((gap >= tol).sum()), float(gap.max()))
     assert frac <= max_frac, frac
     return frac
+
+
+def grad_close(a, b, tol, outlier_frac=2e-3, outlier_tol=None):
+    """Max-normalised gradient comparison that tolerates a small share of elements in a non-smooth regime of the loss
+    (e.g. robust-L1 arguments below eps, where d/dx sqrt(x^2 + eps^2) ~ x / eps turns 1e-5 of input rounding into
+    1e-2 of gradient): all but ``outlier_frac`` of the elements within ``tol`` of the largest reference magnitude,
+    and every element within ``outlier_tol`` (default 25 * tol).  Returns (quantile error, max error)."""
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    err = (a - b).abs() / (b.abs().max() + 1e-30)
+    k = max(1, int(err.numel() * (1 - outlier_frac)))
+    q = float(err.kthvalue(k).values)
+    mx = float(err.max())
+    assert q < tol, "quantile error %.3e >= %.3e" % (q, tol)
+    assert mx < (outlier_tol if outlier_tol is not None else 25 * tol), "max error %.3e" % mx
+    return q, mx
