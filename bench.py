@@ -429,6 +429,17 @@ def main():
             line["roofline_conv"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS * world,
                                      "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                      "what": "reference-algorithmic conv FLOPs (SURVEY section 6) / whole step time"}
+            mpath = os.path.join(ROOT, "profiles", "mfma.json")
+            if os.path.exists(mpath) and world == 1:
+                # PMC evidence (separate rocprofv3 --pmc pass, profiles/r02): MFMA-busy cycles of one step, summed over
+                # the 1024 SIMDs; one busy cycle = 1024 bf16 FLOP, so this is the EXECUTED matrix work of the step
+                with open(mpath) as f:
+                    mf = json.load(f)
+                busy = mf["mfma_busy_cycles_per_step"]
+                line["roofline_conv"]["pmc"] = {
+                    "mfma_busy_frac_of_step": round(busy / (ms * 1e-3 * mf["clock_ghz"] * 1e9 * mf["simds"]), 4),
+                    "executed_tflop_per_step": round(busy * 1024 / 1e12, 2),
+                    "mfma_util_inside_conv_kernels": mf["mfma_util_conv_kernels"], "source": mf["source"]}
         if world == 1 and not args.no_cpu_baseline:
             del model, step, graph, graph_b, graphed_step, run
             torch.cuda.empty_cache()
