@@ -72,7 +72,10 @@ def parse():
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--syncbn", default="off", choices=["on", "off"],
-                   help="N > 1 only: torch SyncBatchNorm as in the config (eager step) or local BN (HIP-graph step)")
+                   help="N > 1: batch statistics over all ranks as in the config (syncbn=True; the hand-written BatchNorm passes "
+                        "with one small all-reduce per layer and direction) or local statistics (default, 12 images per GPU)")
+    p.add_argument("--grad-sync", default="auto", choices=["auto", "overlap-graph", "two-graph", "eager"],
+                   help="N > 1 gradient exchange (auto: overlap-graph, falling back to two-graph, then eager)")
     p.add_argument("--miopen-find", default="config", choices=["config", "on", "off"],
                    help="torch.backends.cudnn.benchmark = MIOpen find mode; default: the config's cudnn_benchmark")
     return p.parse_args()
@@ -270,66 +273,127 @@ def main():
     B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
     torch.manual_seed(1024)
     model = build_model(cfg, dev, channels_last=True)
-    # N > 1: SyncBatchNorm costs ~400 latency-bound collectives per step inside the compute stream
-    #  and keeps the step out of a HIP graph; B = 12 per GPU is enough for local
-    # batch statistics, so the benchmark default is local BN ("--syncbn on" restores the config's SyncBN).
     use_syncbn = args.syncbn == "on"
     dtype = torch.bfloat16 if args.dtype == "bf16" else None
-    split_graph = (world > 1 or args.split_timing) and not use_syncbn and not args.no_graph
-    # flat parameter store (tripled_amd/flat_amp.py).  N > 1: fp32 parameters, flat fp32 gradient buffer filled by
-    # batched concatenations after backward -- no wrapper, no per-parameter accumulate kernels, the all-reduce runs
-    # on the flat buffer.  --flat: additionally a bf16 working copy of the conv weights (41.0 vs 41.3 ms/step at C2;
-    # opt-in until its checkpoint path exists).
-    use_flat = dtype is not None and not use_syncbn and (args.flat or (world > 1 and not args.no_graph))
-    if world > 1 and not use_flat:
-        from mmcv.parallel import MMDistributedDataParallel
-        if use_syncbn:
-            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        # eager: the bucketed all-reduce overlaps backward (autograd hooks); split-graph: it runs between
-        # the forward+backward graph and the clip+Adam graph
-        model = MMDistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
-                                          find_unused_parameters=cfg.get("find_unused_parameters", False),
-                                          overlap=not split_graph)
-        model.train()
-    elif world > 1:
-        # flat path: rank 0's initial weights to everyone, then no wrapper at all -- the gradient exchange is
-        # FlatMixedPrecision.allreduce() on one contiguous fp32 buffer
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
+    dp = world > 1 or os.environ.get("TD_FORCE_DP") == "1"      # TD_FORCE_DP: rehearse the N > 1 code path in a one-rank group
+    if dp and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]))
-    step = TrainStep(model, cfg, batch, dtype, flat=("lowp" if args.flat else "fp32") if use_flat else False)
-
-    # warm-up (and capture) on a side stream: autograd's AccumulateGrad nodes then belong to a
-    # non-default stream, which whole-step graph capture requires
-    graphed_step, graphed = None, False
     side = torch.cuda.Stream()
-    # strict dispatch: any layer of the step that would silently route a HIP tensor to an ATen composition raises
+    cap = side if CAPTURE_STREAM == "side" else None
     dispatch.reset()
-    dispatch.set_strict(not args.allow_fallbacks)
-    warm_up(step, max(args.warmup, 1), side)
-    td_calls_per_step = sum(dispatch.hip_calls.values()) // max(args.warmup, 1)
-    loss_after_warmup = step.check_finite("warm-up")
-    if not args.no_graph and (world == 1 or split_graph):
-        # N > 1: every collective of the warm-up has completed (synchronize above) and the ranks line up before
-        # capturing; "thread_local" keeps the process group's watchdog thread (event queries) from
-        # invalidating the capture -- no collective is issued inside either graph
-        mode = "global" if world == 1 else "thread_local"
-        if world > 1:
+    dispatch.set_strict(not args.allow_fallbacks)    # a layer that would route a HIP tensor to an ATen composition raises
+
+    # Gradient-exchange modes for N > 1, tried in this order; every rank must agree on the outcome:
+    #   overlap-graph  the bucket engine's all-reduces are issued from autograd hooks while backward is still running
+    #                  (RCCL on the process group's side stream) and the WHOLE step -- collectives included -- is one HIP graph
+    #   two-graph      forward+backward graph | eager bucketed all-reduce of the flat gradient buffer | clip+Adam graph
+    #   eager          bucket engine with overlapped all-reduces, no graph
+    nccl = dp and dist.get_backend() == "nccl"
+    if not dp:
+        modes = ["single-flat" if args.flat else "single"]
+    elif args.no_graph:
+        modes = ["eager"]
+    elif args.grad_sync != "auto":
+        modes = [args.grad_sync]
+    else:
+        # both graph forms are brought up, validated and timed for a few steps; the faster one runs the benchmark
+        # (collectives can only be captured on RCCL: a gloo rehearsal skips the first form)
+        modes = (["overlap-graph"] if nccl else []) + ["two-graph"]
+    import copy
+    base_model = model
+
+    def bring_up(mode):
+        """Build the step for ``mode`` on its own copy of the model; returns a dict or raises."""
+        net = copy.deepcopy(base_model)
+        wrapped, flat_kind, split = net, False, False
+        if use_syncbn and dp:
+            from mono.model.networks import enable_sync_batchnorm
+            enable_sync_batchnorm(net, force=world == 1)
+        if mode in ("overlap-graph", "eager"):
+            from mmcv.parallel import MMDistributedDataParallel
+            wrapped = MMDistributedDataParallel(net, device_ids=[dev.index], broadcast_buffers=False,
+                                                find_unused_parameters=cfg.get("find_unused_parameters", False),
+                                                overlap=True, engine_at_world_1=world == 1)
+            wrapped.train()
+        elif mode == "two-graph":
+            # no wrapper: rank 0's weights to everyone, gradients gathered into one flat fp32 buffer after backward
+            for t in list(net.parameters()) + list(net.buffers()):
+                dist.broadcast(t.data, 0)
+            flat_kind, split = ("lowp" if args.flat else "fp32"), True
+        elif mode == "single-flat":
+            flat_kind = "lowp"
+        elif mode == "single" and args.split_timing:
+            flat_kind, split = "fp32", True
+        st = TrainStep(wrapped, cfg, batch, dtype, flat=flat_kind)
+        dispatch.hip_calls.clear()
+        warm_up(st, max(args.warmup, 1), side)
+        calls = sum(dispatch.hip_calls.values()) // max(args.warmup, 1)
+        after_warmup = st.check_finite("warm-up")
+        gs = None
+        if mode != "eager" and not args.no_graph:
+            if dp:      # the warm-up's collectives have completed and the ranks line up before capturing;
+                dist.barrier()      # "thread_local": the process group's watchdog thread may query events meanwhile
+                torch.cuda.synchronize()
+            gs = capture_step(st, stream=cap, split=split, capture_error_mode="thread_local" if dp else "global")
+        return dict(mode=mode, model=net, step=st, graphed=gs, calls=calls, loss_after_warmup=after_warmup)
+
+    def trial_ms(cand, iters=5):
+        run_ = cand["graphed"] if cand["graphed"] is not None else cand["step"]
+        if dp:
             dist.barrier()
-            torch.cuda.synchronize()
-        # capture stream: see DESIGN.md section 6 ("side" = the warm-up stream, a linear single-stream graph;
-        # "default" = PyTorch's capture stream, one event fork/join per parameter gradient)
-        cap = side if CAPTURE_STREAM == "side" else None
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(iters):
+            run_()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0_) / iters * 1e3], device=dev, dtype=torch.float64)
+        if dp:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    candidates, trials = [], {}
+    for mode in modes:
+        ok, cand = True, None
         try:
-            graphed_step = capture_step(step, stream=cap, split=split_graph, capture_error_mode=mode)
-            graphed = True
+            cand = bring_up(mode)
         except NonFiniteLossError:
             raise
-        except Exception as e:      # capture is an optimisation; report and continue eagerly
-            if rank == 0:
-                print("HIP graph capture unavailable (%s: %s); timing eager launches" % (type(e).__name__, e),
-                      file=sys.stderr)
-            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001 -- this form is not available here
+            ok = False
+            print("rank %d: step mode %r unavailable (%s: %s)" % (rank, mode, type(e).__name__, str(e)[:300]), file=sys.stderr)
+        if dp:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0)
+        if ok:
+            if len(modes) > 1:
+                trials[mode] = round(trial_ms(cand), 3)
+            candidates.append(cand)
+    if not candidates and dp and "eager" not in modes:
+        candidates.append(bring_up("eager"))
+    if not candidates:
+        raise SystemExit("bench.py: no step mode could be brought up")
+    best = min(candidates, key=lambda c: trials.get(c["mode"], 0.0))
+    used_mode, model, step, graphed_step = best["mode"], best["model"], best["step"], best["graphed"]
+    graphed = graphed_step is not None
+    td_calls_per_step, loss_after_warmup = best["calls"], best["loss_after_warmup"]
+    for c in candidates:
+        if c is not best:
+            c.clear()
+    del candidates, base_model
+    if dp and world > 1:
+        # the replicas must hold identical parameters after the captured steps
+        chk = torch.stack([p_.detach().double().sum() for p_ in model.parameters()]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(hi - lo) > 1e-6 * max(1.0, abs(float(hi))):
+            raise SystemExit("bench.py: INVALID RUN: replicas diverged under step mode %r" % used_mode)
+    split_graph = graphed and graphed_step.graph_b is not None
+    use_flat = step.flat is not None
     graph = graphed_step.graph if graphed else None
     graph_b = graphed_step.graph_b if graphed else None
 
@@ -389,10 +453,13 @@ def main():
             "config": {"workload": "%s %dx%d bs=%d/GPU (%s), fwd+bwd+clip+Adam" % (
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
                 "parallelism": "dp%d" % world, "hip_graph": graphed,
-                "syncbn": bool(use_syncbn and world > 1),
-                "grad_sync": ("none" if world == 1 else ("bucketed RCCL all-reduce of the flat gradient buffer between two HIP graphs"
-                                                          if graphed else ("bucketed RCCL all-reduce after backward" if use_flat
-                                                                           else "bucketed RCCL all-reduce overlapped with backward"))),
+                "syncbn": bool(use_syncbn and dp),
+                "grad_sync": {"single": "none", "single-flat": "none",
+                              "overlap-graph": "bucketed RCCL all-reduce overlapped with backward on the process group's side "
+                                               "stream, captured with the whole step in one HIP graph",
+                              "two-graph": "bucketed RCCL all-reduce of the flat gradient buffer between two HIP graphs",
+                              "eager": "bucketed RCCL all-reduce overlapped with backward (eager step)"}[used_mode],
+                "step_mode": used_mode, "step_mode_trials_ms": trials or None,
                 "h2d_in_step": bool(args.h2d), "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
                 "capture_stream": CAPTURE_STREAM if graphed else None,
                 "fallbacks": sum(dispatch.fallbacks.values()), "td_abi_calls_per_step": td_calls_per_step,
@@ -445,7 +512,7 @@ def main():
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         # the result line is out; a peer that tears its sockets down first must not turn into a failed run
         try:
             dist.barrier()

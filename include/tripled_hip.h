@@ -235,6 +235,33 @@ int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const flo
               float* dgamma, float* dbeta, float* workspace, td_stream_t stream);
 
 /*
+ * The same normalisation with statistics synchronised over the data-parallel ranks (the reference trains with
+ * syncbn=True: torch.nn.SyncBatchNorm.convert_sync_batchnorm, mono/apis/trainer.py:156-157).  The caller
+ * all-reduces (SUM) the [groups, C, 2] per-channel sums and the row count between the two stages; everything
+ * heavy stays in the kernels of td_bn_fwd / td_bn_bwd:
+ *   td_bn_sync_fwd_sums   sums[g,c,:] = (sum x, sum x^2) over this rank's rows
+ *   td_bn_sync_fwd_apply  mean / invstd / running statistics from the GLOBAL sums and `count` (device scalar:
+ *                         global rows per group), then y as in td_bn_fwd
+ *   td_bn_sync_bwd_sums   sums[g,c,:] = (sum g, sum g * (x - mean)),  g = dy masked by the ReLU
+ *   td_bn_sync_bwd_dx     dgamma / dbeta from the LOCAL sums (the gradient all-reduce averages them like every
+ *                         parameter gradient), dx from the GLOBAL sums; coef: [groups, C, 3] scratch
+ *   workspace: td_bn_workspace_floats(M, groups, C) floats.
+ */
+int td_bn_sync_fwd_sums(const void* x, int dtype, long long M, int groups, int C, float* sums, float* workspace,
+                        td_stream_t stream);
+int td_bn_sync_fwd_apply(const void* x, const void* residual, int dtype, const float* sums, const float* count,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                         float eps, int relu, long long M, int groups, int C, void* y, float* save_mean,
+                         float* save_invstd, td_stream_t stream);
+int td_bn_sync_bwd_sums(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C,
+                        float* sums, float* workspace, td_stream_t stream);
+int td_bn_sync_bwd_dx(const void* dy, const void* x, const void* y, int dtype, const float* local_sums,
+                      const float* global_sums, const float* count, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C,
+                      void* dx, void* dresidual, float* dgamma, float* dbeta, float* coef, td_stream_t stream);
+
+/*
  * Edge-aware regulariser on C-channel feature maps: get_feature_regularization_loss,
  * mono/model/mono_fm_joint/net.py:309-330 (six stencil terms |d_k F| * exp(-a * mean_c |d_k I|)).
  *

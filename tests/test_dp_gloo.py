@@ -163,3 +163,55 @@ def _worker_deferred(rank, world, port):
 
 def test_two_rank_deferred_allreduce_and_flat_store():
     mp.spawn(_worker_deferred, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_syncbn(rank, world, port):
+    """enable_sync_batchnorm on CPU ranks (torch-op staging of the same algorithm the HIP kernels implement): the
+    two half-batches must normalise exactly like one BatchNorm over the whole batch, forward and backward, including
+    stacked passes (bn_groups) and the running statistics."""
+    sys.path.insert(0, ROOT)
+    import tripled_amd  # noqa: F401
+    from mono.model import networks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mono.apis import init_dist
+    init_dist("pytorch", backend="gloo")
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(9)
+    full = torch.randn(8, 64, 5, 7, generator=g)
+    up = torch.randn(8, 64, 5, 7, generator=g)
+    for groups in (1, 2):
+        bn = networks.BatchNorm(64)
+        ref = torch.nn.BatchNorm2d(64)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(64, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(64, generator=g))
+            ref.load_state_dict(bn.state_dict())
+        assert networks.enable_sync_batchnorm(torch.nn.Sequential(bn)) == 1
+        # rank r owns samples [r::2] of every stacked pass
+        per = 8 // groups
+        mine = torch.cat([full[k * per:(k + 1) * per][rank::world] for k in range(groups)], 0).clone().requires_grad_(True)
+        mine_up = torch.cat([up[k * per:(k + 1) * per][rank::world] for k in range(groups)], 0)
+        with networks.bn_groups(groups):
+            y = bn(mine)
+        (y * mine_up).sum().backward()
+        xr = full.clone().requires_grad_(True)
+        yr = torch.cat([ref(xr[k * per:(k + 1) * per]) for k in range(groups)], 0)      # groups separate passes
+        (yr * up).sum().backward()
+        want_y = torch.cat([yr[k * per:(k + 1) * per][rank::world] for k in range(groups)], 0)
+        want_dx = torch.cat([xr.grad[k * per:(k + 1) * per][rank::world] for k in range(groups)], 0)
+        assert torch.allclose(y, want_y, atol=2e-5), float((y - want_y).abs().max())
+        assert torch.allclose(mine.grad, want_dx, atol=2e-5), float((mine.grad - want_dx).abs().max())
+        assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5)
+        assert torch.allclose(bn.running_var, ref.running_var, atol=1e-5)
+        # parameter gradients are local sums: their sum over the ranks is the single-process gradient
+        gw, gb = bn.weight.grad.clone(), bn.bias.grad.clone()
+        dist.all_reduce(gw)
+        dist.all_reduce(gb)
+        assert torch.allclose(gw, ref.weight.grad, atol=2e-4) and torch.allclose(gb, ref.bias.grad, atol=2e-4)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm():
+    port = _free_port()
+    mp.spawn(_worker_syncbn, args=(2, port), nprocs=2, join=True)

@@ -148,3 +148,38 @@ def test_deferred_allreduce_and_flat_store(nccl_group):
     flat.step()
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(p).all()) for p in net2.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu,with_res,groups", [(True, True, 1), (True, False, 2), (False, False, 1)])
+def test_sync_batchnorm_kernels_one_rank(nccl_group, dtype, relu, with_res, groups):
+    """The staged (sums -> RCCL all-reduce -> apply / dx) form of the BatchNorm kernels in a one-rank group must equal
+    the fused local form bit for bit in the forward and to rounding in the backward."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    g = torch.Generator().manual_seed(1)
+    N, C, H, W = 4, 128, 9, 13
+    mk = lambda: torch.randn(N, C, H, W, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    x, res, up = mk(), (mk() if with_res else None), mk()
+    w = (torch.rand(C, generator=g) + 0.5).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    outs = []
+    for sync in (False, True):
+        xi = x.clone().requires_grad_(True)
+        ri = res.clone().requires_grad_(True) if res is not None else None
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+        if sync:
+            y = ops.sync_batchnorm_act(xi, wi, bi, rm, rv, 0.1, 1e-5, None, residual=ri, relu=relu, groups=groups)
+        else:
+            y = ops.batchnorm_act(xi, wi, bi, rm, rv, 0.1, 1e-5, residual=ri, relu=relu, groups=groups)
+        (y.float() * up.float()).sum().backward()
+        outs.append((y.detach().float(), xi.grad.float(), wi.grad, bi.grad, rm, rv, ri.grad.float() if ri is not None else None))
+    a, s = outs
+    assert torch.equal(a[0], s[0])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((a[1] - s[1]).abs().max()) <= tol * float(a[1].abs().max())
+    assert torch.allclose(a[2], s[2], rtol=1e-4, atol=1e-3) and torch.allclose(a[3], s[3], rtol=1e-4, atol=1e-3)
+    assert torch.allclose(a[4], s[4], atol=1e-6) and torch.allclose(a[5], s[5], atol=1e-6)
+    if with_res:
+        assert torch.equal(a[6], s[6])

@@ -153,6 +153,76 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_fwd_kernel(const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross-rank (synchronised) statistics: the partial sums of this rank are reduced to per-channel sums, the
+// caller all-reduces them over the data-parallel group (2*G*C floats), and the finalize runs on the GLOBAL sums
+// with the global row count.  Same kernels either side (bn_partials / bn_apply / bn_dx).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BN_FIN_THREADS) void bn_reduce_partials_kernel(const float* __restrict__ ws, int S, int C, int G,
+                                                                           float* __restrict__ sums /* [G,C,2] */) {
+  for (int grp = 0; grp < G; ++grp) {
+    float A, B;
+    bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
+    if (threadIdx.x < 64) {
+      const size_t c = (size_t)grp * C + blockIdx.x * 64 + threadIdx.x;
+      sums[c * 2 + 0] = A;
+      sums[c * 2 + 1] = B;
+    }
+    __syncthreads();
+  }
+}
+
+// mean / invstd / running statistics from global (sum x, sum x^2) over `count` rows (count: device scalar, the
+// all-reduced row count, so that ranks with different batch sizes stay correct)
+__global__ __launch_bounds__(64) void bn_stats_from_sums_kernel(const float* __restrict__ sums, const float* __restrict__ count,
+                                                               int C, int G, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const double M = (double)count[0];
+  for (int grp = 0; grp < G; ++grp) {
+    const size_t i = (size_t)grp * C + c;
+    const double m = (double)sums[i * 2] / M;
+    double var = (double)sums[i * 2 + 1] / M - m * m;
+    var = var > 0.0 ? var : 0.0;
+    save_mean[i] = (float)m;
+    save_invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unbiased = M > 1.0 ? var * (M / (M - 1.0)) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+// dgamma / dbeta from the LOCAL sums (the parameter gradients are averaged by the gradient all-reduce like every
+// other parameter), dx coefficients from the GLOBAL sums and the global row count
+__global__ __launch_bounds__(64) void bn_coef_from_sums_kernel(const float* __restrict__ local, const float* __restrict__ global,
+                                                              const float* __restrict__ count, int C, int G,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float inv_m = 1.f / count[0];
+  float dg_tot = 0.f, db_tot = 0.f;
+  for (int grp = 0; grp < G; ++grp) {
+    const size_t i = (size_t)grp * C + c;
+    const float is = invstd[i], mu = mean[i];
+    dg_tot += local[i * 2 + 1] * is;
+    db_tot += local[i * 2];
+    const float A = global[i * 2], dg = global[i * 2 + 1] * is;
+    const float k0 = gamma[c] * is;
+    const float k1 = -k0 * is * dg * inv_m;
+    coef[i * 3 + 0] = k0;
+    coef[i * 3 + 1] = k1;
+    coef[i * 3 + 2] = -k0 * A * inv_m - k1 * mu;
+  }
+  dgamma[c] = dg_tot;
+  dbeta[c] = db_tot;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -342,6 +412,51 @@ static int run_bn_bwd(const void* dy, const void* x, const void* y, const float*
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
+// ---- staged entry points for synchronised statistics ----
+template <typename T>
+static int run_bn_local_sums(int mode, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
+                             const float* mean, const float* invstd, int relu, long long M, int G, int C, float* sums, float* ws,
+                             hipStream_t st) {
+  const long long Mg = M / G;
+  const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S_eff = (int)((Mg + rps - 1) / rps);
+  if (mode == 0)
+    hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
+                       (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C,
+                       rps, 0, ws);
+  else
+    hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
+                       (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, G, sums);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+template <typename T>
+static int run_bn_sync_apply(const void* x, const void* res, const float* sums, const float* count, const float* gamma, const float* beta,
+                             float* rmean, float* rvar, float momentum, float eps, int relu, long long M, int G, int C, void* y,
+                             float* save_mean, float* save_invstd, hipStream_t st) {
+  const long long Mg = M / G;
+  hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3(C / 64), dim3(64), 0, st, sums, count, C, G, eps, momentum, rmean, rvar, save_mean,
+                     save_invstd);
+  const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)x,
+                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+template <typename T>
+static int run_bn_sync_dx(const void* dy, const void* x, const void* y, const float* local, const float* global, const float* count,
+                          const float* gamma, const float* beta, const float* mean, const float* invstd, int relu, long long M, int G,
+                          int C, void* dx, void* dres, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+  const long long Mg = M / G;
+  hipLaunchKernelGGL(bn_coef_from_sums_kernel, dim3(C / 64), dim3(64), 0, st, local, global, count, C, G, gamma, mean, invstd, dgamma, dbeta,
+                     coef);
+  const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)dy,
+                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
 }  // namespace td
 
 static bool bn_shape_ok(long long M, int G, int C) { return G >= 1 && G <= 64 && M > 0 && C > 0 && M % G == 0; }
@@ -382,5 +497,71 @@ extern "C" int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype
   if (dtype == TD_DTYPE_F32)
     return td::run_bn_bwd<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, dx, dresidual, dgamma, dbeta, workspace,
                                  (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+// ---- synchronised (cross-rank) statistics: local sums -> [caller: all-reduce] -> apply / dx --------------------
+
+extern "C" int td_bn_sync_fwd_sums(const void* x, int dtype, long long M, int groups, int C, float* sums, float* workspace,
+                                   td_stream_t stream) {
+  if (!x || !sums || !workspace || !bn_shape_ok(M, groups, C)) return TD_ERR_BAD_ARG;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_local_sums<__hip_bfloat16>(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, M, groups, C, sums, workspace,
+                                                 (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_local_sums<float>(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, M, groups, C, sums, workspace,
+                                        (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_bn_sync_fwd_apply(const void* x, const void* residual, int dtype, const float* sums, const float* count,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                    float eps, int relu, long long M, int groups, int C, void* y, float* save_mean, float* save_invstd,
+                                    td_stream_t stream) {
+  if (!x || !sums || !count || !gamma || !beta || !y || !save_mean || !save_invstd || !bn_shape_ok(M, groups, C)) return TD_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TD_ERR_BAD_ARG;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_sync_apply<__hip_bfloat16>(x, residual, sums, count, gamma, beta, running_mean, running_var, momentum, eps, relu, M,
+                                                 groups, C, y, save_mean, save_invstd, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_sync_apply<float>(x, residual, sums, count, gamma, beta, running_mean, running_var, momentum, eps, relu, M, groups, C,
+                                        y, save_mean, save_invstd, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_bn_sync_bwd_sums(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta,
+                                   const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C,
+                                   float* sums, float* workspace, td_stream_t stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !sums || !workspace || !bn_shape_ok(M, groups, C)) return TD_ERR_BAD_ARG;
+  if (relu < 0 || relu > 1 || (relu && !y && !beta)) return TD_ERR_BAD_ARG;
+  if (relu && !y) relu = 2;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_local_sums<__hip_bfloat16>(1, x, dy, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, sums, workspace,
+                                                 (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_local_sums<float>(1, x, dy, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, sums, workspace,
+                                        (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_bn_sync_bwd_dx(const void* dy, const void* x, const void* y, int dtype, const float* local_sums, const float* global_sums,
+                                 const float* count, const float* gamma, const float* beta, const float* save_mean,
+                                 const float* save_invstd, int relu, long long M, int groups, int C, void* dx, void* dresidual,
+                                 float* dgamma, float* dbeta, float* coef, td_stream_t stream) {
+  if (!dy || !x || !local_sums || !global_sums || !count || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !coef ||
+      !bn_shape_ok(M, groups, C))
+    return TD_ERR_BAD_ARG;
+  if (relu < 0 || relu > 1 || (relu && !y && (!beta || dresidual))) return TD_ERR_BAD_ARG;
+  if (relu && !y) relu = 2;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_sync_dx<__hip_bfloat16>(dy, x, y, local_sums, global_sums, count, gamma, beta, save_mean, save_invstd, relu, M, groups,
+                                              C, dx, dresidual, dgamma, dbeta, coef, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_sync_dx<float>(dy, x, y, local_sums, global_sums, count, gamma, beta, save_mean, save_invstd, relu, M, groups, C, dx,
+                                     dresidual, dgamma, dbeta, coef, (hipStream_t)stream);
   return TD_ERR_UNSUPPORTED;
 }

@@ -146,9 +146,12 @@ def _finish_runner(runner, cfg, data_loaders):
 
 def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
     data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, dist=True)]
-    if cfg.get("syncbn", False):
-        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     dev = _device()
+    if cfg.get("syncbn", False):
+        # this build's BatchNorm layers exchange their statistics themselves (hand-written passes + one small
+        # all-reduce per layer and direction); any other normalisation layer takes torch's SyncBatchNorm
+        from mono.model.networks import enable_sync_batchnorm
+        enable_sync_batchnorm(model)
     model = configure_execution(model, cfg, dev)
     model = MMDistributedDataParallel(model, find_unused_parameters=cfg.get("find_unused_parameters", False),
                                       device_ids=[dev.index] if dev.type == "cuda" else None,

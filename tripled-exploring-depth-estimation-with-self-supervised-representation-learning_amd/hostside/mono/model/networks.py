@@ -59,6 +59,7 @@ class BatchNorm(nn.BatchNorm2d):
     normalisation in every ResNet block into the same pass (TD_NO_FUSED_BN=1 restores ATen/MIOpen)."""
 
     _pending = 0
+    _sync = None            # (process_group,) when the batch statistics span the data-parallel ranks (enable_sync_batchnorm)
 
     def _hip_ok(self, x):
         if not (x.is_cuda and self.training and self.track_running_stats and self.momentum is not None
@@ -71,9 +72,15 @@ class BatchNorm(nn.BatchNorm2d):
             g = _BN_GROUPS[0]
             self._pending += g
             if self._hip_ok(x):
+                if self._sync is not None:
+                    return _ops().sync_batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                                     self.momentum, self.eps, self._sync[0], groups=g)
                 return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                             self.momentum, self.eps, groups=g)
             _fell_back("BatchNorm", x)
+            if self._sync is not None:
+                return _ATenSyncBatchNorm.apply(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                                self.momentum, self.eps, g, self._sync[0])
             if g > 1:      # stacked passes without the HIP kernels: one ATen call per pass, in order
                 return torch.cat([F.batch_norm(c, self.running_mean, self.running_var, self.weight, self.bias, True,
                                                self.momentum, self.eps) for c in x.chunk(g, 0)], 0)
@@ -86,12 +93,86 @@ class BatchNorm(nn.BatchNorm2d):
         if self._hip_ok(x):
             g = _BN_GROUPS[0]
             self._pending += g
+            if self._sync is not None:
+                return _ops().sync_batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                                 self.momentum, self.eps, self._sync[0], residual=residual, relu=relu, groups=g)
             return _ops().batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                         self.momentum, self.eps, residual=residual, relu=relu, groups=g)
         return _plain_bn_act(self, x, residual, relu)      # (BatchNorm.forward reports the fallback)
 
 
 _BN_GROUPS = [1]
+
+
+class _ATenSyncBatchNorm(torch.autograd.Function):
+    """Synchronised batch normalisation from torch ops, device-agnostic (CPU ranks over gloo in the tests; HIP tensors
+    in a layout the kernels do not take).  Same staging as tripled_amd.ops.sync_batchnorm_act: local per-channel sums
+    -> one all-reduce -> normalise; the parameter gradients stay local (the gradient all-reduce averages them)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, groups, process_group):
+        import torch.distributed as dist
+        n, c = x.shape[0], x.shape[1]
+        xs = x.float().reshape(groups, n // groups, c, -1)
+        packed = torch.cat([xs.sum((1, 3)).reshape(-1), (xs * xs).sum((1, 3)).reshape(-1),
+                            xs.new_full((1,), float(xs.shape[1] * xs.shape[3]))])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=process_group)
+        count = packed[-1]
+        mean = (packed[:groups * c] / count).reshape(groups, 1, c, 1)
+        var = ((packed[groups * c:2 * groups * c] / count).reshape(groups, 1, c, 1) - mean * mean).clamp_min(0)
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                for g in range(groups):     # one momentum update per stacked pass, in order
+                    running_mean.mul_(1 - momentum).add_(momentum * mean[g].reshape(-1))
+                    running_var.mul_(1 - momentum).add_(momentum * (var[g].reshape(-1) * (count / (count - 1))))
+        xhat = (xs - mean) * invstd
+        y = xhat * weight.float().reshape(1, 1, c, 1) + bias.float().reshape(1, 1, c, 1)
+        ctx.save_for_backward(xhat, invstd, weight, count)
+        ctx.shape, ctx.dtype, ctx.groups, ctx.group = x.shape, x.dtype, groups, process_group
+        return y.reshape(x.shape).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        xhat, invstd, weight, count = ctx.saved_tensors
+        groups, c = ctx.groups, ctx.shape[1]
+        g = dy.float().reshape(xhat.shape)
+        sg, sgx = g.sum((1, 3)), (g * xhat).sum((1, 3))               # [groups, c]
+        total = torch.cat([sg.reshape(-1), sgx.reshape(-1)])
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
+        tg = (total[:groups * c] / count).reshape(groups, 1, c, 1)
+        tgx = (total[groups * c:] / count).reshape(groups, 1, c, 1)
+        dx = (g - tg - xhat * tgx) * (invstd * weight.float().reshape(1, 1, c, 1))
+        return (dx.reshape(ctx.shape).to(ctx.dtype), sgx.sum(0).to(weight.dtype), sg.sum(0).to(weight.dtype),
+                None, None, None, None, None, None)
+
+
+def enable_sync_batchnorm(model, process_group=None, force=False):
+    """The reference's ``syncbn=True`` (torch.nn.SyncBatchNorm.convert_sync_batchnorm, mono/apis/trainer.py:156-157) for
+    this build's BatchNorm modules: batch statistics are summed over the ranks of ``process_group`` (one all-reduce of
+    2*C+1 floats per layer and direction) while the passes over the activations stay in the hand-written kernels.
+    A one-rank group leaves the layers local unless ``force`` (tests).  Returns the number of layers switched."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("enable_sync_batchnorm needs an initialised process group")
+    if dist.get_world_size(process_group) == 1 and not force:
+        return 0
+    n = 0
+    for m in model.modules():
+        if isinstance(m, BatchNorm):
+            m._sync = (process_group,)
+            n += 1
+
+    def foreign(parent):
+        # normalisation layers that are not this build's BatchNorm (the optional 1x1 skip heads) take torch's SyncBatchNorm
+        for name, child in parent.named_children():
+            if isinstance(child, nn.modules.batchnorm._BatchNorm) and not isinstance(child, (BatchNorm, nn.SyncBatchNorm)):
+                setattr(parent, name, nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+            else:
+                foreign(child)
+    foreign(model)
+    return n
 
 
 class bn_groups:

@@ -353,6 +353,85 @@ def batchnorm_act(x, weight, bias, running_mean, running_var, momentum, eps, res
     return _BatchNormAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups)
 
 
+class _SyncBatchNormAct(torch.autograd.Function):
+    """_BatchNormAct with the per-channel statistics summed over a process group between the two kernel stages."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, process_group):
+        import torch.distributed as dist
+        lib = native.load()
+        N, C, H, W = x.shape
+        M = N * H * W
+        code = native.DTYPE_CODES[x.dtype]
+        packed = torch.empty(groups * C * 2 + 1, device=x.device, dtype=torch.float32)      # sums + row count: ONE collective
+        ws = torch.empty(lib.td_bn_workspace_floats(M, groups, C), device=x.device, dtype=torch.float32)
+        st = native.stream()
+        native.check(lib.td_bn_sync_fwd_sums(_raw(x), code, M, groups, C, native.ptr(packed), native.ptr(ws), st),
+                     "td_bn_sync_fwd_sums")
+        packed[-1:].fill_(float(M // groups))
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=process_group)
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        mean = torch.empty(groups * C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(groups * C, device=x.device, dtype=torch.float32)
+        native.check(lib.td_bn_sync_fwd_apply(_raw(x), _raw(residual) if residual is not None else None, code, native.ptr(packed),
+                                              _raw(packed[-1:]), native.ptr(weight), native.ptr(bias),
+                                              native.ptr(running_mean) if running_mean is not None else None,
+                                              native.ptr(running_var) if running_var is not None else None,
+                                              float(momentum), float(eps), int(relu), M, groups, C, _raw(y), native.ptr(mean),
+                                              native.ptr(invstd), native.stream()), "td_bn_sync_fwd_apply")
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, bias, mean, invstd, packed[-1:].clone())
+        ctx.relu, ctx.has_res, ctx.groups, ctx.group = bool(relu), residual is not None, groups, process_group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        lib = native.load()
+        x, y, weight, bias, mean, invstd, count = ctx.saved_tensors
+        N, C, H, W = x.shape
+        M = N * H * W
+        G = ctx.groups
+        code = native.DTYPE_CODES[x.dtype]
+        if dy.dtype != x.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        local = torch.empty(G * C * 2, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.td_bn_workspace_floats(M, G, C), device=x.device, dtype=torch.float32)
+        yp = _raw(y) if y is not None else None
+        native.check(lib.td_bn_sync_bwd_sums(_raw(dy), _raw(x), yp, code, native.ptr(weight), native.ptr(bias), native.ptr(mean),
+                                             native.ptr(invstd), int(ctx.relu), M, G, C, native.ptr(local), native.ptr(ws),
+                                             native.stream()), "td_bn_sync_bwd_sums")
+        total = local.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=ctx.group)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if (ctx.has_res and ctx.relu) else None
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        coef = torch.empty(G * C * 3, device=x.device, dtype=torch.float32)
+        native.check(lib.td_bn_sync_bwd_dx(_raw(dy), _raw(x), yp, code, native.ptr(local), native.ptr(total), native.ptr(count),
+                                           native.ptr(weight), native.ptr(bias), native.ptr(mean), native.ptr(invstd), int(ctx.relu),
+                                           M, G, C, _raw(dx), _raw(dres) if dres is not None else None, native.ptr(dgamma),
+                                           native.ptr(dbeta), native.ptr(coef), native.stream()), "td_bn_sync_bwd_dx")
+        if ctx.has_res and not ctx.relu:
+            dres = dy
+        return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None, None, None
+
+
+def sync_batchnorm_act(x, weight, bias, running_mean, running_var, momentum, eps, process_group, residual=None, relu=False,
+                       groups=1):
+    """batchnorm_act with batch statistics over ALL ranks of ``process_group`` (the reference's syncbn=True,
+    mono/apis/trainer.py:156-157): one all-reduce of 2*groups*C+1 floats each way, the passes over the activation
+    in the same hand-written kernels as the local form."""
+    if x.shape[0] % groups:
+        raise ValueError("batch %d is not %d stacked passes" % (x.shape[0], groups))
+    if not batchnorm_act_supported(x, weight):
+        raise native.NativeLibraryError("sync_batchnorm_act needs a channels_last f32/bf16 HIP tensor with C % 64 == 0")
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape
+                                 or not residual.is_contiguous(memory_format=torch.channels_last)):
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return _SyncBatchNormAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups,
+                                   process_group)
+
+
 def edge_weights(img_at_scale, a, scale6):
     """Per-pixel, per-term image weights scale_k * exp(-a * mean_c |d_k I|) -> [B,6,h,w] (no gradient)."""
     import ctypes
