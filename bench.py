@@ -63,7 +63,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--prune-extractor-tail", action="store_true",
                    help="skip the ResNet tails whose output the reference discards (net.py:221); NOT the headline configuration")
-    p.add_argument("--h2d", action="store_true", help="include the host-to-device copy of every batch in the timed step")
+    p.add_argument("--h2d", nargs="?", const="float32", default=None, choices=["float32", "uint8"],
+                   help="include the host-to-device copy of every batch in the timed step: the reference's float32 wire format "
+                        "(two float copies per frame) or this build's uint8 format (bytes + device-side ToTensor / colour jitter)")
     p.add_argument("--split-timing", action="store_true", help="two graphs (fwd+bwd | clip+Adam) and report each")
     p.add_argument("--flat", action="store_true", help="flat bf16/fp32 parameter store (tripled_amd/flat_amp.py) instead of autocast + per-parameter Adam")
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
@@ -409,15 +411,35 @@ def main():
               file=sys.stderr)
     run = graphed_step if graphed else step
     if args.h2d:
-        # PCIe-inclusive variant: every step first copies the batch from pinned host
-        # memory into the step's input buffers (the headline `value` is measured without this flag)
-        host = {k: v.detach().cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v)}
+        # PCIe-inclusive variants (the headline `value` is measured without this flag): every step first
+        # copies the batch from pinned host memory into the step's input buffers
         replay = run
+        if args.h2d == "float32":
+            host = {k: v.detach().cpu().pin_memory() for k, v in batch.items() if torch.is_tensor(v)}
 
-        def run():
-            for k, h in host.items():
-                batch[k].copy_(h, non_blocking=True)
-            replay()
+            def run():
+                for k, h in host.items():
+                    batch[k].copy_(h, non_blocking=True)
+                replay()
+        else:
+            from tripled_amd import ops as _ops
+            frames = list(m["frame_ids"])
+            u8 = torch.cat([(batch[("color", f, 0)] * 255).round().clamp(0, 255).to(torch.uint8) for f in frames], 0).cpu().pin_memory()
+            aug_h = torch.zeros(len(frames) * B, 9).pin_memory()
+            other = {k: v.detach().cpu().pin_memory() for k, v in batch.items()
+                     if torch.is_tensor(v) and not (isinstance(k, tuple) and k[0] in ("color", "color_aug"))}
+            u8_d, aug_d = torch.empty_like(u8, device=dev), torch.empty_like(aug_h, device=dev)
+
+            def run():
+                u8_d.copy_(u8, non_blocking=True)
+                aug_d.copy_(aug_h, non_blocking=True)
+                for k, h in other.items():
+                    batch[k].copy_(h, non_blocking=True)
+                color, color_aug = _ops.color_jitter_expand(u8_d, aug_d)
+                for i, f in enumerate(frames):
+                    batch[("color", f, 0)].copy_(color[i * B:(i + 1) * B])
+                    batch[("color_aug", f, 0)].copy_(color_aug[i * B:(i + 1) * B])
+                replay()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -460,7 +482,7 @@ def main():
                               "two-graph": "bucketed RCCL all-reduce of the flat gradient buffer between two HIP graphs",
                               "eager": "bucketed RCCL all-reduce overlapped with backward (eager step)"}[used_mode],
                 "step_mode": used_mode, "step_mode_trials_ms": trials or None,
-                "h2d_in_step": bool(args.h2d), "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
+                "h2d_in_step": args.h2d or False, "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
                 "capture_stream": CAPTURE_STREAM if graphed else None,
                 "fallbacks": sum(dispatch.fallbacks.values()), "td_abi_calls_per_step": td_calls_per_step,
                 "loss_after_warmup": round(loss_after_warmup, 6), "final_loss": round(final_loss, 6), "valid": True},

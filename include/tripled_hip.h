@@ -383,6 +383,18 @@ int td_pose_bwd(const float* axisangle, const float* translation, const int* inv
                 int n_pairs, int B, const float* gT, const float* gP, float* g_axisangle,
                 float* g_translation, td_stream_t stream);
 
+/*
+ * Input expansion on the device: uint8 frames -> float images + their colour-jittered copies.  Replaces ToTensor and
+ * ColorJitter per frame on the host (MonoDataset.preprocess, mono/datasets/mono_dataset.py:83-101; parameters drawn at
+ * :146-152) and the float32 upload of both copies (change_input_variable, mono/apis/trainer.py:19-29).
+ *   frames_u8  [N,3,H,W] uint8 (N = frames x samples)
+ *   aug        [N,9] float: (enabled, op0..op3, brightness, contrast, saturation, hue); ops 0..3 = brightness, contrast,
+ *              saturation, hue, applied in the listed order (torchvision ColorJitter's float formulas)
+ *   means_scratch [N] floats;  color, color_aug [N,3,H,W] float32 in [0,1] (out)
+ */
+int td_color_jitter(const uint8_t* frames_u8, const float* aug, int N, int H, int W, float* means_scratch, float* color,
+                    float* color_aug, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,8 +50,12 @@ def change_input_variable(data):
     dev = _device()
     if isinstance(data, dict):
         for k, v in data.items():
-            if "kp" not in k:
+            if isinstance(k, tuple) and k and k[0] == "color_u8":       # 'uint8' wire format: bytes until expanded on the device
+                data[k] = torch.as_tensor(v).to(dev, non_blocking=True)
+            elif "kp" not in k:
                 data[k] = torch.as_tensor(v).to(dev, dtype=torch.float32, non_blocking=True)
+        from mono.datasets import expand_device_batch
+        expand_device_batch(data)
     else:
         data[0] = [torch.as_tensor(img).to(dev, dtype=torch.float32, non_blocking=True) for img in data[0]]
     return data

@@ -61,8 +61,19 @@ def _predict_one(model, sample):
     dev = next(model.parameters()).device
     batch = {}
     for k, v in sample.items():
-        t = torch.as_tensor(v).float()
-        batch[k] = t.unsqueeze(0).to(dev)
+        t = torch.as_tensor(v)
+        if isinstance(k, tuple) and k and k[0] == "color_u8":
+            if dev.type == "cuda":                       # 'uint8' wire format: expanded by the HIP kernel below
+                batch[k] = t.unsqueeze(0).to(dev)
+            else:                                        # evaluation on the host: plain ToTensor (no jitter in validation)
+                img = t.float().div(255.0).unsqueeze(0)
+                batch[("color", k[1], 0)], batch[("color_aug", k[1], 0)] = img, img
+            continue
+        batch[k] = t.float().unsqueeze(0).to(dev)
+    if dev.type == "cuda":
+        from mono.datasets import expand_device_batch
+        expand_device_batch(batch)
+    batch.pop("aug", None)
     with torch.no_grad():
         result = model(batch)
     scaled, _ = disp_to_depth(result[("disp", 0, 0)].float())

@@ -2,3 +2,4 @@ from .loader import DistributedGroupSampler, DistributedSampler, GroupSampler, b
 from .get_dataset import get_dataset  # noqa: F401
 from .synthetic import SyntheticTripletDataset, synthetic_batch  # noqa: F401
 from .prefetch import DevicePrefetcher  # noqa: F401
+from .device_expand import expand_device_batch, has_uint8_frames  # noqa: F401

@@ -27,7 +27,7 @@ def get_dataset(cfg, training=True):
             height=cfg["height"], width=cfg["width"],
             frame_ids=cfg["frame_ids"] if training else [0],
             erase_shape=cfg.get("erase_shape", (16, 16)), erase_count=cfg.get("erase_count", 16),
-            with_mask=True, with_gt=not training)
+            with_mask=True, with_gt=not training, wire=cfg.get("wire", "float32"), augment=training)
         ds.substituted_for = name if substitute else None
         return ds
     if name in ("kitti", "kitti_inpaint"):

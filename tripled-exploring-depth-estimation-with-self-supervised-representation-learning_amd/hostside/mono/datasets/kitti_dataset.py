@@ -36,8 +36,13 @@ def pil_loader(path):
 
 def to_tensor(img):
     """PIL RGB -> float [3,H,W] in [0,1] (torchvision ToTensor semantics)."""
-    arr = np.asarray(img, dtype=np.uint8)
-    return torch.from_numpy(arr).permute(2, 0, 1).float().div_(255.0)
+    return to_uint8(img).float().div_(255.0)
+
+
+def to_uint8(img):
+    """PIL RGB -> uint8 [3,H,W] (the 'uint8' wire format: 3 bytes per pixel instead of 2 x 12)."""
+    arr = np.array(img, dtype=np.uint8)
+    return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
 
 
 def _shift_hue(img, hue_factor):
@@ -55,6 +60,10 @@ class ColorJitter:
         self.order = torch.randperm(4).tolist()
         self.factors = [float(torch.empty(1).uniform_(*brightness)), float(torch.empty(1).uniform_(*contrast)),
                         float(torch.empty(1).uniform_(*saturation)), float(torch.empty(1).uniform_(*hue))]
+
+    def as_row(self):
+        """(enabled, op0..op3, brightness, contrast, saturation, hue): the parameter row td_color_jitter consumes."""
+        return torch.tensor([1.0] + [float(o) for o in self.order] + self.factors, dtype=torch.float32)
 
     def __call__(self, img):
         for op in self.order:
@@ -110,6 +119,11 @@ class MonoDataset(Dataset):
         if self.gt_depths is not None:
             inputs["gt_depth"] = self.gt_depths[index]
         jitter = ColorJitter(self.brightness, self.contrast, self.saturation, self.hue) if do_color_aug else None
+        # wire = "uint8": frames travel as bytes, ToTensor and the colour jitter run on the device
+        # (mono.datasets.device_expand / csrc/td_augment.hip); "float32" is the reference's format
+        u8_wire = self.cfg.get("wire", "float32") == "uint8"
+        if u8_wire:
+            inputs["aug"] = jitter.as_row() if jitter is not None else torch.zeros(9)
         for i in self.frame_idxs:
             if i == "s":
                 img = self.get_color(folder, frame_index, {"r": "l", "l": "r"}[side], do_flip)
@@ -119,6 +133,9 @@ class MonoDataset(Dataset):
                 except (FileNotFoundError, OSError):            # sequence boundary: repeat the centre frame
                     img = self.get_color(folder, frame_index, side, do_flip)
             img = self.resize(img)
+            if u8_wire:
+                inputs[("color_u8", i)] = to_uint8(img)
+                continue
             inputs[("color", i, 0)] = to_tensor(img)
             inputs[("color_aug", i, 0)] = to_tensor(jitter(img)) if jitter is not None else inputs[("color", i, 0)].clone()
         K = self.K.copy()
@@ -162,7 +179,7 @@ class KITTIInpaintDataset(KITTIDataset):
     erase_count == 1), reference kitti_dataset.py:167-182."""
 
     def postprocess(self, inputs):
-        image = inputs[("color", 0, 0)]
+        image = inputs[("color", 0, 0)] if ("color", 0, 0) in inputs else inputs[("color_u8", 0)]
         eh, ew = self.cfg["erase_shape"]
         count = self.cfg["erase_count"]
         mask = torch.ones(image.shape, dtype=torch.uint8)

@@ -2,7 +2,8 @@
 blocking ``.float().cuda()`` from pageable memory (mono/apis/trainer.py:19-29) -- ~120 MB per step at
 B=12 192x640, serialised with the compute stream.  ``DevicePrefetcher`` wraps any loader of batch dicts:
 the next batch is copied from pinned memory on a side HIP stream while the current step runs, and is
-handed over already on the device (float32), so ``change_input_variable`` finds nothing left to do."""
+handed over already on the device (float32; uint8 frames of the 'uint8' wire format stay bytes and are expanded by
+``mono.datasets.device_expand`` in batch_processor), so ``change_input_variable`` finds nothing left to copy."""
 import torch
 
 
@@ -23,7 +24,9 @@ class DevicePrefetcher:
                 if isinstance(v, torch.Tensor):
                     if not v.is_pinned():
                         v = v.pin_memory()
-                    out[k] = v.to(self.device, non_blocking=True).float()
+                    v = v.to(self.device, non_blocking=True)
+                    # the uint8 wire format stays bytes until the device-side expansion (device_expand.py)
+                    out[k] = v if (isinstance(k, tuple) and k and k[0] == "color_u8") else v.float()
                 else:
                     out[k] = v
         return out

@@ -27,7 +27,7 @@ def _smooth_canvas(g, h, w):
 
 
 def make_sample(seed, height, width, frame_ids=(0, -1, 1), erase_shape=(16, 16), erase_count=16, max_shift=4,
-                with_mask=True):
+                with_mask=True, wire="float32", augment=False):
     g = torch.Generator().manual_seed(int(seed))
     canvas = _smooth_canvas(g, height + 2 * max_shift, width + 2 * max_shift)
     sample = {}
@@ -38,8 +38,18 @@ def make_sample(seed, height, width, frame_ids=(0, -1, 1), erase_shape=(16, 16),
             dy = int(torch.randint(0, 2 * max_shift + 1, (1,), generator=g))
             dx = int(torch.randint(0, 2 * max_shift + 1, (1,), generator=g))
         img = canvas[:, dy:dy + height, dx:dx + width].contiguous()
+        if wire == "uint8":      # the byte wire format of the KITTI loader (kitti_dataset.py), expanded on the device
+            sample[("color_u8", f)] = (img * 255.0).round().clamp_(0, 255).to(torch.uint8)
+            continue
         sample[("color", f, 0)] = img
         sample[("color_aug", f, 0)] = img.clone()
+    if wire == "uint8":
+        row = torch.zeros(9)
+        if augment and float(torch.rand(1, generator=g)) > 0.5:
+            u = lambda lo, hi: lo + (hi - lo) * float(torch.rand(1, generator=g))
+            row = torch.tensor([1.0] + [float(v) for v in torch.randperm(4, generator=g)] +
+                               [u(0.8, 1.2), u(0.8, 1.2), u(0.8, 1.2), u(-0.1, 0.1)])
+        sample["aug"] = row
     if with_mask:
         mask = torch.ones(3, height, width)
         eh, ew = erase_shape
@@ -56,7 +66,8 @@ def make_sample(seed, height, width, frame_ids=(0, -1, 1), erase_shape=(16, 16),
 
 class SyntheticTripletDataset(Dataset):
     def __init__(self, length, height, width, frame_ids=(0, -1, 1), erase_shape=(16, 16), erase_count=16,
-                 seed=1000, with_mask=True, with_gt=False):
+                 seed=1000, with_mask=True, with_gt=False, wire="float32", augment=False):
+        self.wire, self.augment = wire, augment
         self.length, self.height, self.width = length, height, width
         self.frame_ids, self.erase_shape, self.erase_count = tuple(frame_ids), tuple(erase_shape), erase_count
         self.seed, self.with_mask, self.with_gt = seed, with_mask, with_gt
@@ -67,7 +78,7 @@ class SyntheticTripletDataset(Dataset):
 
     def __getitem__(self, idx):
         s = make_sample(self.seed + idx, self.height, self.width, self.frame_ids, self.erase_shape,
-                        self.erase_count, with_mask=self.with_mask)
+                        self.erase_count, with_mask=self.with_mask, wire=self.wire, augment=self.augment)
         if self.with_gt:
             g = torch.Generator().manual_seed(self.seed + idx + 7)
             s["gt_depth"] = 2.0 + 60.0 * torch.rand(self.height, self.width, generator=g)

@@ -755,3 +755,22 @@ def pose_transforms(axisangle, translation, K, invert):
     if a.shape[0] % len(invert):
         raise ValueError("pose rows %d are not %d pairs of equal batch" % (a.shape[0], len(invert)))
     return _PoseTransforms.apply(a, t, _f32c(K), [bool(v) for v in invert])
+
+
+def color_jitter_expand(frames_u8, aug):
+    """uint8 frames [N,3,H,W] + per-image jitter parameters [N,9] -> (color, color_aug) float32 [N,3,H,W]
+    (reference: ToTensor + ColorJitter in MonoDataset.preprocess, mono/datasets/mono_dataset.py:83-101)."""
+    lib = native.load()
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[1] != 3:
+        raise ValueError("frames_u8 must be uint8 [N,3,H,W]")
+    frames_u8 = frames_u8.contiguous()
+    aug = _f32c(aug)
+    N, _, H, W = frames_u8.shape
+    if aug.shape != (N, 9):
+        raise ValueError("aug must be [N,9]")
+    color = torch.empty(N, 3, H, W, device=frames_u8.device, dtype=torch.float32)
+    color_aug = torch.empty_like(color)
+    scratch = torch.empty(N, device=frames_u8.device, dtype=torch.float32)
+    native.check(lib.td_color_jitter(native.ptr(frames_u8), native.ptr(aug), N, H, W, native.ptr(scratch), native.ptr(color),
+                                     native.ptr(color_aug), native.stream()), "td_color_jitter")
+    return color, color_aug
