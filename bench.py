@@ -69,6 +69,8 @@ def parse():
     p.add_argument("--split-timing", action="store_true", help="two graphs (fwd+bwd | clip+Adam) and report each")
     p.add_argument("--flat", action="store_true", help="flat bf16/fp32 parameter store (tripled_amd/flat_amp.py) instead of autocast + per-parameter Adam")
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
+    p.add_argument("--fp8", action="store_true", help="forward GEMM of the eligible 1x1 convolutions on the fp8 MFMA path "
+                                                      "(BASELINE config 5; off by default: measured slower at these sizes, DESIGN.md)")
     p.add_argument("--allow-fallbacks", action="store_true",
                    help="do not fail when a HIP-resident tensor takes an ATen composition instead of a hand-written kernel")
     p.add_argument("--cpu-batch", type=int, default=2)
@@ -274,6 +276,8 @@ def main():
         m["prune_extractor_tail"] = True
     B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
     torch.manual_seed(1024)
+    from mono.model.networks import set_fp8_conv1x1
+    set_fp8_conv1x1(args.fp8)
     model = build_model(cfg, dev, channels_last=True)
     use_syncbn = args.syncbn == "on"
     dtype = torch.bfloat16 if args.dtype == "bf16" else None
@@ -470,7 +474,8 @@ def main():
             "value": round(world * B * args.steps / elapsed, 3),
             "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 convs (MFMA) + f32 loss kernels" if dtype is not None else "f32",
+            "dtype": ("bf16 convs (MFMA) + f32 loss kernels" + (", fp8 forward GEMM of the 1x1 convs" if args.fp8 else ""))
+            if dtype is not None else "f32",
             "data": "synthetic",
             "config": {"workload": "%s %dx%d bs=%d/GPU (%s), fwd+bwd+clip+Adam" % (
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,

@@ -395,6 +395,20 @@ int td_pose_bwd(const float* axisangle, const float* translation, const int* inv
 int td_color_jitter(const uint8_t* frames_u8, const float* aug, int N, int H, int W, float* means_scratch, float* color,
                     float* color_aug, td_stream_t stream);
 
+/*
+ * Per-tensor fp8 quantisation (OCP e4m3fn, saturating) for the fp8 1x1-convolution path (BASELINE config 5).  The
+ * reference has no reduced-precision path (it trains in fp32: mono/apis/trainer.py:147-189); the 1x1 convolutions this
+ * serves are resnet.py:52-86 (Bottleneck conv1/conv3, downsample) and layers.py:110-118 (Conv1x1).
+ *   td_fp8_amax_partials  partials[td_fp8_num_blocks(n)] = per-block max |x|
+ *   td_fp8_quantize       q[i] = e4m3(x[i] * 448 / amax), inv_scale[0] = amax / 448  (amax = max of the partials; the
+ *                         product  q_a . q_b * inv_scale_a * inv_scale_b  is the de-quantised GEMM result)
+ *   x: n elements of dtype TD_DTYPE_F32 / TD_DTYPE_BF16, n % 8 == 0.
+ */
+int td_fp8_num_blocks(long long n);
+int td_fp8_amax_partials(const void* x, int dtype, long long n, float* partials, td_stream_t stream);
+int td_fp8_quantize(const void* x, int dtype, long long n, const float* partials, uint8_t* q, float* inv_scale,
+                    td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ def _device():
 #   channels_last  True (default on a HIP device) -- NHWC weights/activations: the layout the hand-written
 #                  BatchNorm / pool / pad / join kernels and MIOpen's MFMA implicit-GEMM kernels take
 #   strict_dispatch  False -- raise instead of warn when a HIP tensor falls back to an ATen composition
+#   fp8_conv1x1    False -- forward GEMM of the 1x1 convolutions on the fp8 MFMA path (mono.model.networks.set_fp8_conv1x1)
 _MODE = {"autocast": None}
 
 
@@ -41,6 +42,8 @@ def configure_execution(model, cfg, dev):
     if on_gpu:
         from tripled_amd import dispatch
         dispatch.set_strict(bool(cfg.get("strict_dispatch", False)))
+        from mono.model.networks import set_fp8_conv1x1
+        set_fp8_conv1x1(bool(cfg.get("fp8_conv1x1", False)))
     return model
 
 

@@ -239,8 +239,34 @@ RESNET_SPECS = {18: ("basic", (2, 2, 2, 2)), 34: ("basic", (3, 4, 6, 3)),
                 50: ("bottleneck", (3, 4, 6, 3)), 101: ("bottleneck", (3, 4, 23, 3))}
 
 
+_FP8_1X1 = [False]
+
+
+def set_fp8_conv1x1(on):
+    """cfg.fp8_conv1x1 / bench.py --fp8: the forward GEMM of every eligible 1x1 stride-1 convolution (bf16 channels-last
+    activation, Cin % 16 == Cout % 16 == 0) runs on the fp8 MFMA path (tripled_amd.ops.conv1x1_fp8); weights, gradients
+    and the backward stay as they are.  Returns the previous setting."""
+    prev = _FP8_1X1[0]
+    _FP8_1X1[0] = bool(on)
+    return prev
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters and state_dict keys) whose 1x1 stride-1 case can take the fp8 path."""
+
+    def forward(self, x):
+        if _FP8_1X1[0] and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.groups == 1 \
+                and x.is_cuda and torch.is_autocast_enabled():
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            xb = _dense_cl(xb)
+            if _ops().conv1x1_fp8_supported(xb, self.weight):
+                return _ops().conv1x1_fp8(xb, self.weight, self.bias)
+            _fell_back("Conv2d.fp8_1x1", x)
+        return super().forward(x)
+
+
 def _conv(cin, cout, k, stride=1, pad=0, bias=False):
-    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias)
+    return Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias)
 
 
 class BasicBlock(nn.Module):
@@ -459,7 +485,7 @@ class PoseDecoder(nn.Module):
 
     def __init__(self, num_ch_enc, stride=1):
         super().__init__()
-        self.reduce = nn.Conv2d(int(num_ch_enc[-1]), 256, 1)
+        self.reduce = Conv2d(int(num_ch_enc[-1]), 256, 1)
         self.conv1 = nn.Conv2d(256, 256, 3, stride, 1)
         self.conv2 = nn.Conv2d(256, 256, 3, stride, 1)
         self.conv3 = nn.Conv2d(256, 6, 1)
@@ -491,7 +517,7 @@ def upsample(x):
 class Conv1x1(nn.Module):
     def __init__(self, in_channels, out_channels, bias=False):
         super().__init__()
-        self.conv = nn.Conv2d(int(in_channels), int(out_channels), kernel_size=1, stride=1, bias=bias)
+        self.conv = Conv2d(int(in_channels), int(out_channels), kernel_size=1, stride=1, bias=bias)
 
     def forward(self, x):
         return self.conv(x)

@@ -68,6 +68,9 @@ SIGNATURES = {
     "td_bn_sync_fwd_apply": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P]),
     "td_bn_sync_bwd_sums": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P]),
     "td_bn_sync_bwd_dx": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "td_fp8_num_blocks": (_I, [ctypes.c_longlong]),
+    "td_fp8_amax_partials": (_I, [_P, _I, ctypes.c_longlong, _P, _P]),
+    "td_fp8_quantize": (_I, [_P, _I, ctypes.c_longlong, _P, _P, _P, _P]),
     "td_color_jitter": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     "td_l1map_fwd": (_I, [_P, _I, _LLARR, _P, _I, _I, _I, _I, _F, _P, _P]),
     "td_l1map_bwd": (_I, [_P, _I, _LLARR, _P, _P, _I, _I, _I, _I, _F, _P, _P]),

@@ -774,3 +774,63 @@ def color_jitter_expand(frames_u8, aug):
     native.check(lib.td_color_jitter(native.ptr(frames_u8), native.ptr(aug), N, H, W, native.ptr(scratch), native.ptr(color),
                                      native.ptr(color_aug), native.stream()), "td_color_jitter")
     return color, color_aug
+
+
+def quantize_fp8(t):
+    """Per-tensor current-scaling fp8 quantisation of a dense f32/bf16 HIP tensor: (q float8_e4m3fn with t's shape,
+    inv_scale [1] float32 with t ~= q * inv_scale).  Two launches, no host round trip (csrc/td_fp8.hip)."""
+    lib = native.load()
+    if not (t.is_cuda and t.dtype in native.DTYPE_CODES and t.numel() % 8 == 0 and torch.ops.aten.is_non_overlapping_and_dense(t)):
+        raise native.NativeLibraryError("quantize_fp8 needs a dense f32/bf16 HIP tensor with numel % 8 == 0")
+    n = t.numel()
+    code = native.DTYPE_CODES[t.dtype]
+    partials = torch.empty(lib.td_fp8_num_blocks(n), device=t.device, dtype=torch.float32)
+    q = torch.empty_strided(t.size(), t.stride(), device=t.device, dtype=torch.uint8)
+    inv_scale = torch.empty(1, device=t.device, dtype=torch.float32)
+    st = native.stream()
+    native.check(lib.td_fp8_amax_partials(_raw(t), code, n, native.ptr(partials), st), "td_fp8_amax_partials")
+    native.check(lib.td_fp8_quantize(_raw(t), code, n, native.ptr(partials), _raw(q), native.ptr(inv_scale), st), "td_fp8_quantize")
+    return q.view(torch.float8_e4m3fn), inv_scale
+
+
+class _Conv1x1FP8(torch.autograd.Function):
+    """y = conv2d(x, w[, b]) for a 1x1 stride-1 convolution on channels-last activations, forward GEMM in fp8 on the MFMA
+    (hipBLASLt through torch._scaled_mm, fp32 accumulation, bf16 out); backward in the activation dtype from the
+    saved full-precision operands."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, C, H, W = x.shape
+        K = weight.shape[0]
+        w = weight.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        xq, sx = quantize_fp8(x)
+        wq, sw = quantize_fp8(w)
+        a = xq.permute(0, 2, 3, 1).reshape(N * H * W, C)                 # [M, Cin] row-major view of the NHWC memory
+        b = wq.reshape(K, C).t()                                         # [Cin, Cout] column-major
+        y = torch._scaled_mm(a, b, scale_a=sx, scale_b=sw, bias=bias.to(x.dtype) if bias is not None else None,
+                             out_dtype=x.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.wdtype = weight.dtype
+        return y.reshape(N, H, W, K).permute(0, 3, 1, 2)                 # logical NCHW, channels-last memory
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1],
+                                                          False, [0, 0], 1, [True, True, ctx.has_bias])
+        return gx, gw.to(ctx.wdtype), (gb.to(ctx.wdtype) if ctx.has_bias else None)
+
+
+def conv1x1_fp8_supported(x, weight):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+            and weight.dim() == 4 and weight.shape[2:] == (1, 1) and weight.shape[1] == x.shape[1]
+            and x.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0 and hasattr(torch, "float8_e4m3fn"))
+
+
+def conv1x1_fp8(x, weight, bias=None):
+    """1x1 stride-1 convolution with the forward GEMM on the fp8 MFMA path (BASELINE config 5); see _Conv1x1FP8."""
+    if not conv1x1_fp8_supported(x, weight):
+        raise native.NativeLibraryError("conv1x1_fp8 needs a channels_last bf16 HIP activation, Cin % 16 == Cout % 16 == 0")
+    return _Conv1x1FP8.apply(x, weight, bias)
