@@ -77,6 +77,17 @@ def main():
     def want(k):
         return only is None or k in only
 
+    if only is not None and "calib" in only:
+        # calibration of the FETCH_SIZE / WRITE_SIZE counters for THIS access width: td_l1map_fwd on one-channel tensors
+        # streams 2 x 4 B/pixel in and 4 B/pixel out, one dword per lane, far past the 256 MiB Infinity Cache
+        n = 48 * 1024 * 1024
+        pa, pb = torch.rand(1, 1, 4096, n // 4096, device=dev), torch.rand(1, 1, 4096, n // 4096, device=dev)
+        po = torch.empty_like(pa)
+        strides = native.strides_array(pa)
+        res["calib_dword_stream"] = timeit(lambda: native.check(lib.td_l1map_fwd(
+            native.ptr(pa), 0, strides, native.ptr(pb), 1, 1, 4096, n // 4096, 1.0, native.ptr(po), st), "calib"), args.iters)
+        print(json.dumps({"us": res, "calib_read_bytes": 8 * n, "calib_write_bytes": 4 * n}))
+        return
     if want("identity"):
         res["identity"] = timeit(lambda: native.check(lib.td_photo_identity(
             native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "id"), args.iters)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/kernel_bench.py, corrected as
+MI355X_MICROARCH.md's HBM section prescribes: the counters are in KB; FETCH_SIZE under-counts streaming reads on gfx950 and
+"other access widths are uncalibrated: calibrate on a known byte count in your own access pattern" -- the calibration is
+the `calib` case of kernel_bench.py (one dword per lane, 402.7 MB read / 201.3 MB written by td_l1map_fwd).
+
+  python tools/traffic_from_pmc.py <pmc_dir_of_kernel_passes> <pmc_dir_of_calibration_passes> > profiles/traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def collect(root):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def mean_kb(acc, needle, counter, largest=True):
+    vals = []
+    for name, c in acc.items():
+        if needle in name and counter in c:
+            vals += c[counter]
+    if not vals:
+        return None
+    if largest:      # scale 0 = the launches with the largest counts (4 scales per step)
+        vals = sorted(vals)[-max(1, len(vals) // 4):]
+    return sum(vals) / len(vals)
+
+
+def main():
+    kern, cal = collect(sys.argv[1]), collect(sys.argv[2])
+    n = 48 * 1024 * 1024
+    f_raw = mean_kb(cal, "l1map_kernel", "FETCH_SIZE", largest=False) * 1024
+    w_raw = mean_kb(cal, "l1map_kernel", "WRITE_SIZE", largest=False) * 1024
+    kf, kw = 8.0 * n / f_raw, 4.0 * n / w_raw
+    out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB x 1024), mean per launch at B=12 192x640 scale 0, "
+                    "multiplied by the calibration factors measured on a dword-per-lane stream of known size "
+                    "(MI355X_MICROARCH.md, HBM: FETCH_SIZE under-counts on gfx950; calibrate in your own access pattern)",
+           "_calibration": {"true_read_bytes": 8 * n, "raw_FETCH_bytes": round(f_raw), "fetch_factor": round(kf, 4),
+                            "true_write_bytes": 4 * n, "raw_WRITE_bytes": round(w_raw), "write_factor": round(kw, 4)},
+           "_raw": {}}
+    for key, needle in (("photo_bwd_s0", "photo_bwd_kernel<2>"), ("photo_fwd_s0", "photo_fwd_kernel<2, 3"),
+                        ("identity", "photo_fwd_kernel<2, 0")):
+        f, w = mean_kb(kern, needle, "FETCH_SIZE"), mean_kb(kern, needle, "WRITE_SIZE")
+        if f is None or w is None:
+            continue
+        out["_raw"][key] = {"FETCH_bytes": round(f * 1024), "WRITE_bytes": round(w * 1024)}
+        out[key] = round(f * 1024 * kf + w * 1024 * kw)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
