@@ -233,6 +233,7 @@ def cpu_baseline(cfg_path, batch_size, steps):
         avail = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(avail, int(os.environ.get("TD_CPU_THREADS", "16")))))
     cfg = Config.fromfile(cfg_path)
+    gpu_batch = cfg.model["imgs_per_gpu"]
     cfg.model["imgs_per_gpu"] = batch_size
     torch.manual_seed(1024)
     model = build_model(cfg, torch.device("cpu"), channels_last=False)
@@ -246,8 +247,9 @@ def cpu_baseline(cfg_path, batch_size, steps):
         step()
     dt = time.time() - t0
     return dict(value=round(batch_size * steps / dt, 4), unit="imgs/s", cores=torch.get_num_threads(), kind="port",
-                sample="%s fp32 on CPU, B=%d of the %dx%d batch, 1 warm-up + %d timed steps (fwd+bwd+clip+Adam), "
-                       "oracle loss path" % (cfg.model["name"], batch_size, cfg.model["height"], cfg.model["width"], steps))
+                sample="%s fp32 on CPU, B=%d images per step (a sample of the GPU leg's B=%d batch: NOT the same batch size), %dx%d, "
+                       "1 warm-up + %d timed steps (fwd+bwd+clip+Adam), oracle loss path" % (
+                           cfg.model["name"], batch_size, gpu_batch, cfg.model["height"], cfg.model["width"], steps))
 
 
 def main():
