@@ -21,8 +21,15 @@ hip_calls = collections.Counter()
 fallbacks = collections.Counter()
 
 
+_trace = os.environ.get("TD_TRACE_CALLS", "0") == "1"
+
+
 def hip(name, n=1):
     hip_calls[name] += n
+    if _trace:      # fault triage: with AMD_SERIALIZE_KERNEL=3 the last line printed names the entry point that faulted
+        import sys
+        sys.stderr.write("td-call %s\n" % name)
+        sys.stderr.flush()
 
 
 def fallback(site, why=""):

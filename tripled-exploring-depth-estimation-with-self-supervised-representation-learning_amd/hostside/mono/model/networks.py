@@ -527,6 +527,42 @@ def _round8(n):
     return (n + 7) // 8 * 8
 
 
+class _ConvImmediate(torch.autograd.Function):
+    """conv2d whose forward AND backward run with MIOpen's find mode off (immediate-mode solver choice).
+
+    ROCm 7.2: the tuning search of ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC for the backward-data problem
+    `convbfp16 -n 4 -c 16 -H 322 -W 1026 -k 16 -y 3 -x 3` (NHWC) -- iconv1 of the image decoders at the 320x1024
+    configuration -- ends in a GPU memory access fault (MIOPEN_LOG_LEVEL=5 trace: the fault follows
+    "Starting search: ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC" for exactly this problem); with the search skipped the
+    same layer runs.  The flag is read when the op executes, so the backward needs the guard too."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            y = F.conv2d(x, w, b)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False):
+            gx, gw, gb = torch.ops.aten.convolution_backward(gy, x, w, [w.shape[0]] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1],
+                                                              False, [0, 0], 1, [True, True, ctx.has_bias])
+        return gx, gw, (gb if ctx.has_bias else None)
+
+
+def _conv2d_guarded(x, w, b):
+    """F.conv2d, except for the narrow (<= 16 channels) layers on inputs wider than 1024 columns: see _ConvImmediate."""
+    if x.is_cuda and x.shape[1] <= 16 and w.shape[0] <= 16 and x.shape[3] > 1024 and torch.backends.cudnn.benchmark:
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            x, w, b = x.to(dt), w.to(dt), (b.to(dt) if b is not None else None)
+        return _ConvImmediate.apply(x, w, b)
+    return F.conv2d(x, w, b)
+
+
 class Conv3x3(nn.Module):
     """3x3 conv after a 1-pixel reflection (or zero) pad.
 
@@ -562,7 +598,7 @@ class Conv3x3(nn.Module):
         cout, cin = w.shape[0], w.shape[1]
         cin_p, cout_p = _round8(cin), _round8(cout)
         if cin_p == cin and cout_p == cout and x.shape[1] == cin:
-            return self.conv(self._pad_input(x))
+            return _conv2d_guarded(self._pad_input(x), w, b)
         if x.shape[1] == cin and cin_p != cin:               # caller did not pre-pad the channels
             x = torch.cat((x, x.new_zeros(x.shape[0], cin_p - cin, x.shape[2], x.shape[3])), 1)
         if x.shape[1] != cin_p:
@@ -572,7 +608,7 @@ class Conv3x3(nn.Module):
         w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
         if b is not None and cout_p != cout:
             b = F.pad(b, (0, cout_p - cout))
-        y = F.conv2d(self._pad_input(x), w, b)
+        y = _conv2d_guarded(self._pad_input(x), w, b)
         return y[:, :cout] if cout_p != cout else y
 
 
@@ -583,7 +619,7 @@ class Conv3x3(nn.Module):
         if (self.use_refl and x.is_cuda and x.shape[1] == cin and cin % 8 == 0 and self.conv.weight.shape[0] % 8 == 0
                 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous(memory_format=torch.channels_last)
                 and not os.environ.get("TD_NO_FUSED_UPSAMPLE")):
-            return self.conv(_ops().up2_reflpad1(x))
+            return _conv2d_guarded(_ops().up2_reflpad1(x), self.conv.weight, self.conv.bias)
         _fell_back("Conv3x3.forward_up", x)
         return self.forward(upsample(x))
 
