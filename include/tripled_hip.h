@@ -207,6 +207,13 @@ int td_join_fwd(const void* a, const void* b, const void* tail, int dtype, long 
                 void* out, td_stream_t stream);
 int td_join_bwd(const void* grad_out, int dtype, long long npix, int C0, int C1, int C2, void* grad_a, void* grad_b,
                 void* grad_tail, td_stream_t stream);
+/* The same with the middle operand `b_half` [N,H/2,W/2,C1] up-sampled x2 (nearest) on the fly: the DepthDecoder's
+ * torch.cat((reduce(l), upsample(x), disp), 1) without materialising upsample(x) (depth_decoder.py:89-103; 189 MB at the
+ * last stage of C2).  H, W even.  The backward sums the four output pixels of every low-resolution pixel. */
+int td_join_up2_fwd(const void* a, const void* b_half, const void* tail, int dtype, int N, int H, int W, int C0, int C1,
+                    int C2, void* out, td_stream_t stream);
+int td_join_up2_bwd(const void* grad_out, int dtype, int N, int H, int W, int C0, int C1, int C2, void* grad_a,
+                    void* grad_b_half, void* grad_tail, td_stream_t stream);
 
 /*
  * Training-mode BatchNorm2d on channels-last activations with the residual add and ReLU of the ResNet

@@ -143,3 +143,29 @@ def test_up2_reflpad1_matches_aten(shape, dtype):
     ref.backward(g.float())
     tol = 1e-5 if dtype == torch.float32 else 4e-2        # up to 16 bf16 gradients summed in fp32, rounded once
     assert torch.allclose(x.grad.float(), xr.grad, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 6, 10, 1), (3, 256, 256, 12, 20, 1), (12, 256, 256, 24, 80, 1), (1, 8, 24, 2, 4, 5)])
+def test_join_channels_up2_matches_cat_of_upsampled(shape, dtype):
+    """torch.cat((a, interpolate(b, scale_factor=2, mode="nearest"), tail, zeros), 1) without the up-sampled tensor
+    (depth_decoder.py:89-103), forward and the three gradients (the low-resolution one sums four pixels)."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    N, C0, C1, H, W, C2 = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    mk = lambda c, h, w: torch.randn(N, c, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    a, b, t = mk(C0, H, W), mk(C1, H // 2, W // 2), mk(C2, H, W)
+    ins = [v.clone().requires_grad_(True) for v in (a, b, t)]
+    ref_in = [v.clone().requires_grad_(True) for v in (a, b, t)]
+    out = ops.join_channels_up2(*ins)
+    up = torch.nn.functional.interpolate(ref_in[1], scale_factor=2, mode="nearest")
+    ref = torch.cat((ref_in[0], up, ref_in[2], torch.zeros(N, 8 - C2, H, W, device="cuda", dtype=dtype)), 1)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out, ref)
+    go = torch.randn(ref.shape, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    out.backward(go)
+    ref.backward(go)
+    assert torch.equal(ins[0].grad, ref_in[0].grad) and torch.equal(ins[2].grad, ref_in[2].grad)
+    tol = 1e-6 if dtype == torch.float32 else 2e-2            # bf16: four-term sum in f32 here, pairwise bf16 in ATen
+    assert float((ins[1].grad.float() - ref_in[1].grad.float()).abs().max()) <= tol * max(1.0, float(ref_in[1].grad.float().abs().max()))

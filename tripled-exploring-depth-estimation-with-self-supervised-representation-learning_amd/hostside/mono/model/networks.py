@@ -613,13 +613,21 @@ class Conv3x3(nn.Module):
 
 
     def forward_up(self, x):
-        """self(upsample(x)): x2 nearest + reflection pad in one HIP pass when the layout allows it."""
-        cin = self.conv.weight.shape[1]
+        """self(upsample(x)): x2 nearest + reflection pad in one HIP pass when the layout allows it (output channels
+        padded to a multiple of 8 like forward(), e.g. the 1-channel disparity heads)."""
+        w, b = self.conv.weight, self.conv.bias
+        cout, cin = w.shape[0], w.shape[1]
         x = _dense_cl(x)
-        if (self.use_refl and x.is_cuda and x.shape[1] == cin and cin % 8 == 0 and self.conv.weight.shape[0] % 8 == 0
+        low_precision = x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())
+        if (self.use_refl and x.is_cuda and x.shape[1] == cin and cin % 8 == 0 and (cout % 8 == 0 or low_precision)
                 and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous(memory_format=torch.channels_last)
                 and not os.environ.get("TD_NO_FUSED_UPSAMPLE")):
-            return _conv2d_guarded(_ops().up2_reflpad1(x), self.conv.weight, self.conv.bias)
+            cout_p = _round8(cout)
+            if cout_p != cout:
+                w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
+                b = F.pad(b, (0, cout_p - cout)) if b is not None else None
+            y = _conv2d_guarded(_ops().up2_reflpad1(x), w, b)
+            return y[:, :cout] if cout_p != cout else y
         _fell_back("Conv3x3.forward_up", x)
         return self.forward(upsample(x))
 
@@ -736,21 +744,34 @@ class DepthDecoder(nn.Module):
             setattr(self, "disp%d" % i, nn.Sequential(Conv3x3(width, 1), nn.Sigmoid()))
 
     def _stage(self, i, x):
+        """Returns (stage output, disparity, deferred).  deferred = True: the stage output is still at HALF resolution --
+        its x2 nearest up-sampling is folded into the consumers (the disparity head's pad here, the channel join of the
+        next stage), so the up-sampled 256-channel map (189 MB at the last stage of C2) is never materialised."""
         x = F.leaky_relu(getattr(self, "iconv%d" % i)(x))
         x = getattr(self, "crp%d" % i)(x)
         x = F.leaky_relu(getattr(self, "merge%d" % i)(x))
+        head = getattr(self, "disp%d" % i)
         if self.use_shuffle:
             # the reference up-samples stage 1 with up2 (depth_decoder.py:105), kept as is
             x = getattr(self, "up%d" % (2 if i == 1 else i))(x)
+        elif x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) \
+                and x.shape[1] % 8 == 0 and not os.environ.get("TD_NO_FUSED_UPSAMPLE"):
+            return x, head[1](head[0].forward_up(x)), True
         else:
             x = upsample(x)
-        return x, getattr(self, "disp%d" % i)(x)
+        return x, head(x), False
 
     def forward(self, input_features, frame_id=0):
         _, l1, l2, l3, l4 = input_features
         l4 = self.do(l4)
         l3 = self.do(l3)
-        def joined(r, x, d):
+        def joined(r, x, d, deferred):
+            if deferred:
+                tail = d.to(x.dtype)
+                if _ops().join_channels_up2_supported(r, x, tail) and not os.environ.get("TD_NO_CHANNEL_PAD"):
+                    return _ops().join_channels_up2(r, x, tail)
+                _fell_back("DepthDecoder.join_up2", x)
+                x = upsample(x)
             parts = [r, x, d.to(x.dtype)]
             c = sum(p.shape[1] for p in parts)
             if x.is_cuda and c % 8 and x.dtype == torch.bfloat16 and not os.environ.get("TD_NO_CHANNEL_PAD"):
@@ -761,10 +782,10 @@ class DepthDecoder(nn.Module):
                 parts.append(x.new_zeros(x.shape[0], _round8(c) - c, x.shape[2], x.shape[3]))
             return torch.cat(parts, 1)
 
-        x, d4 = self._stage(4, self.reduce4(l4))
-        x, d3 = self._stage(3, joined(self.reduce3(l3), x, d4))
-        x, d2 = self._stage(2, joined(self.reduce2(l2), x, d3))
-        x, d1 = self._stage(1, joined(self.reduce1(l1), x, d2))
+        x, d4, up = self._stage(4, self.reduce4(l4))
+        x, d3, up = self._stage(3, joined(self.reduce3(l3), x, d4, up))
+        x, d2, up = self._stage(2, joined(self.reduce2(l2), x, d3, up))
+        x, d1, up = self._stage(1, joined(self.reduce1(l1), x, d2, up))
         self.outputs = {("disp", frame_id, 3): d4, ("disp", frame_id, 2): d3,
                         ("disp", frame_id, 1): d2, ("disp", frame_id, 0): d1}
         return self.outputs

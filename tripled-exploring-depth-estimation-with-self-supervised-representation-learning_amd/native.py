@@ -45,6 +45,8 @@ SIGNATURES = {
     "td_maxpool3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "td_join_fwd": (_I, [_P, _P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P]),
     "td_join_bwd": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P]),
+    "td_join_up2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "td_join_up2_bwd": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "td_bn_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _I]),
     "td_bn_fwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P]),
     "td_bn_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _P]),

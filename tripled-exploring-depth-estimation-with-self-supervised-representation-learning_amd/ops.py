@@ -272,6 +272,48 @@ class _JoinChannels(torch.autograd.Function):
         return ga, gb, gt
 
 
+class _JoinChannelsUp2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b_half, tail):
+        lib = native.load()
+        N, C0, H, W = a.shape
+        C1, C2 = b_half.shape[1], tail.shape[1]
+        out = torch.empty((N, C0 + C1 + 8, H, W), device=a.device, dtype=a.dtype, memory_format=torch.channels_last)
+        native.check(lib.td_join_up2_fwd(_raw(a), _raw(b_half), _raw(tail), native.DTYPE_CODES[a.dtype], N, H, W, C0, C1, C2,
+                                         _raw(out), native.stream()), "td_join_up2_fwd")
+        ctx.dims = (N, C0, C1, C2, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        N, C0, C1, C2, H, W = ctx.dims
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        mk = lambda c, h, w: torch.empty((N, c, h, w), device=g.device, dtype=g.dtype, memory_format=torch.channels_last)
+        ga, gb, gt = mk(C0, H, W), mk(C1, H // 2, W // 2), mk(C2, H, W)
+        native.check(lib.td_join_up2_bwd(_raw(g), native.DTYPE_CODES[g.dtype], N, H, W, C0, C1, C2, _raw(ga), _raw(gb), _raw(gt),
+                                         native.stream()), "td_join_up2_bwd")
+        return ga, gb, gt
+
+
+def join_channels_up2_supported(a, b_half, tail):
+    cl = lambda t: t.is_contiguous(memory_format=torch.channels_last)
+    return (a.is_cuda and a.dim() == 4 and a.dtype in native.DTYPE_CODES and b_half.dtype == a.dtype and tail.dtype == a.dtype
+            and a.shape[1] % 8 == 0 and b_half.shape[1] % 8 == 0 and 1 <= tail.shape[1] <= 8
+            and a.shape[0] == b_half.shape[0] == tail.shape[0] and a.shape[2:] == tail.shape[2:]
+            and a.shape[2] == 2 * b_half.shape[2] and a.shape[3] == 2 * b_half.shape[3]
+            and cl(a) and cl(b_half) and cl(tail))
+
+
+def join_channels_up2(a, b_half, tail):
+    """torch.cat((a, upsample_x2_nearest(b_half), tail, zeros), 1) up to C0 + C1 + 8 channels, without materialising the
+    up-sampled operand (reference: depth_decoder.py:89-103, where x was up-sampled at the end of the previous stage)."""
+    if not join_channels_up2_supported(a, b_half, tail):
+        raise native.NativeLibraryError("join_channels_up2 needs channels_last f32/bf16 HIP tensors, b at half resolution")
+    return _JoinChannelsUp2.apply(a, b_half, tail)
+
+
 def join_channels_supported(a, b, tail):
     cl = lambda t: t.is_contiguous(memory_format=torch.channels_last)
     return (a.is_cuda and a.dim() == 4 and a.dtype in native.DTYPE_CODES and b.dtype == a.dtype and tail.dtype == a.dtype
