@@ -345,7 +345,9 @@ def main():
             if dp:      # the warm-up's collectives have completed and the ranks line up before capturing;
                 dist.barrier()      # "thread_local": the process group's watchdog thread may query events meanwhile
                 torch.cuda.synchronize()
-            gs = capture_step(st, stream=cap, split=split, capture_error_mode="thread_local" if dp else "global")
+            # captured but NOT replayed yet: under N > 1 a replay executes collectives, so it must not start before every
+            # rank is known to have captured successfully (main loop below)
+            gs = capture_step(st, stream=cap, split=split, capture_error_mode="thread_local" if dp else "global", validate=False)
         return dict(mode=mode, model=net, step=st, graphed=gs, calls=calls, loss_after_warmup=after_warmup)
 
     def trial_ms(cand, iters=5):
@@ -377,6 +379,11 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item() > 0)
         if ok:
+            if cand["graphed"] is not None:
+                for i in range(2):      # validation replays (all ranks together): a captured step that is not finite is an error
+                    cand["graphed"]()
+                    torch.cuda.synchronize()
+                    cand["step"].check_finite("replay %d of the captured step (%s)" % (i, mode))
             if len(modes) > 1:
                 trials[mode] = round(trial_ms(cand), 3)
             candidates.append(cand)
