@@ -67,7 +67,9 @@ def parse():
                    help="include the host-to-device copy of every batch in the timed step: the reference's float32 wire format "
                         "(two float copies per frame) or this build's uint8 format (bytes + device-side ToTensor / colour jitter)")
     p.add_argument("--split-timing", action="store_true", help="two graphs (fwd+bwd | clip+Adam) and report each")
-    p.add_argument("--flat", action="store_true", help="flat bf16/fp32 parameter store (tripled_amd/flat_amp.py) instead of autocast + per-parameter Adam")
+    p.add_argument("--no-flat", action="store_true",
+                   help="autocast + per-parameter fused Adam instead of the flat bf16/fp32 parameter store (tripled_amd/flat_amp.py; "
+                        "the store is the trainer's default with amp='bf16', mono/apis/trainer.py)")
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
     p.add_argument("--fp8", action="store_true", help="forward GEMM of the eligible 1x1 convolutions on the fp8 MFMA path "
                                                       "(BASELINE config 5; off by default: measured slower at these sizes, DESIGN.md)")
@@ -300,8 +302,9 @@ def main():
     #   two-graph      forward+backward graph | eager bucketed all-reduce of the flat gradient buffer | clip+Adam graph
     #   eager          bucket engine with overlapped all-reduces, no graph
     nccl = dp and dist.get_backend() == "nccl"
+    lowp_store = dtype is not None and not args.no_flat
     if not dp:
-        modes = ["single-flat" if args.flat else "single"]
+        modes = ["single-flat" if lowp_store and not args.split_timing else "single"]
     elif args.no_graph:
         modes = ["eager"]
     elif args.grad_sync != "auto":
@@ -330,7 +333,7 @@ def main():
             # no wrapper: rank 0's weights to everyone, gradients gathered into one flat fp32 buffer after backward
             for t in list(net.parameters()) + list(net.buffers()):
                 dist.broadcast(t.data, 0)
-            flat_kind, split = ("lowp" if args.flat else "fp32"), True
+            flat_kind, split = ("lowp" if lowp_store else "fp32"), True
         elif mode == "single-flat":
             flat_kind = "lowp"
         elif mode == "single" and args.split_timing:
@@ -490,6 +493,8 @@ def main():
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
                 "parallelism": "dp%d" % world, "hip_graph": graphed,
                 "syncbn": bool(use_syncbn and dp),
+                "param_store": ("flat fp32 master + bf16 working copy" if step.flat is not None and lowp_store and used_mode != "overlap-graph"
+                                else ("flat fp32" if step.flat is not None else "per-parameter")),
                 "grad_sync": {"single": "none", "single-flat": "none",
                               "overlap-graph": "bucketed RCCL all-reduce overlapped with backward on the process group's side "
                                                "stream, captured with the whole step in one HIP graph",

@@ -44,6 +44,23 @@ def test_argument_validation_without_gpu():
     assert lib.td_photo_identity(None, None, 2, 1, 8, 8, None, None) == -1
     assert lib.td_smooth_finish(None, 1, 8, 8, 1.0, None, None) == -1
     assert b"bad argument" in lib.td_error_string(-1)
+    # round-2 entry points: the same contract (nothing is launched on a bad argument)
+    import ctypes
+    four = (ctypes.c_longlong * 4)(1, 1, 1, 1)
+    two = (ctypes.c_int * 2)(1, 0)
+    assert lib.td_l1map_fwd(None, 0, four, None, 1, 3, 8, 8, 1.0, None, None) == -1
+    assert lib.td_l1map_bwd(None, 0, four, None, None, 1, 3, 8, 8, 1.0, None, None) == -1
+    assert lib.td_rgb2lab(None, 1, 8, 8, 50.0, 50.0, 110.0, None, None) == -1
+    assert lib.td_pose_fwd(None, None, two, None, 2, 4, None, None, None) == -1
+    assert lib.td_pose_bwd(None, None, two, None, 2, 4, None, None, None, None, None) == -1
+    assert lib.td_color_jitter(None, None, 1, 8, 8, None, None, None, None) == -1
+    assert lib.td_fp8_num_blocks(0) == 0 and lib.td_fp8_num_blocks(8192) == 1 and lib.td_fp8_num_blocks(8193) == 2
+    assert lib.td_fp8_amax_partials(None, 1, 64, None, None) == -1
+    assert lib.td_fp8_quantize(None, 1, 64, None, None, None, None) == -1
+    assert lib.td_join_up2_fwd(None, None, None, 1, 1, 4, 4, 8, 8, 1, None, None) == -1
+    assert lib.td_bn_sync_fwd_sums(None, 1, 64, 1, 64, None, None, None) == -1
+    assert lib.td_bn_sync_bwd_dx(None, None, None, 1, None, None, None, None, None, None, None, 0, 64, 1, 64,
+                                 None, None, None, None, None, None) == -1
 
 
 def test_product_fails_loudly_without_hip_device():

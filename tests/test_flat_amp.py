@@ -45,3 +45,74 @@ def test_flat_store_matches_autocast_adam():
         if p.dtype == torch.bfloat16:   # (TD_FLAT_LOWP=0 keeps every parameter fp32)
             assert torch.equal(p.detach(), master.to(torch.bfloat16))
         assert off % 8 == 0
+
+
+def _flat_step(flat, net, x):
+    flat.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss = net(x).float().square().mean()
+    loss.backward()
+    flat.collect()
+    flat.allreduce()
+    flat.step()
+    return float(loss.detach())
+
+
+def test_checkpoint_layout_and_resume():
+    """A checkpoint written through the flat store has the reference's layout (fp32 weights under the module's keys,
+    per-parameter Adam state in model.parameters() order): it resumes (a) into another flat store, continuing
+    bit-identically, and (b) into a plain model + torch.optim.Adam, continuing like the autocast path."""
+    x = torch.randn(4, 3, 12, 16)
+    net = _net()
+    flat = FlatMixedPrecision(net, lr=1e-2, max_norm=0.5)
+    for _ in range(3):
+        _flat_step(flat, net, x)
+    sd = flat.module_state_dict(net)
+    osd = flat.optimizer_state_dict(net)
+    plain_keys = list(_net().state_dict().keys())
+    assert list(sd.keys()) == plain_keys and all(v.dtype == torch.float32 for k, v in sd.items() if v.is_floating_point())
+    n_params = len([p for p in net.parameters() if p.requires_grad])
+    assert sorted(osd["state"].keys()) == list(range(n_params)) and osd["param_groups"][0]["params"] == list(range(n_params))
+    assert all(osd["state"][i]["exp_avg"].shape == p.shape for i, p in enumerate(net.parameters()))
+
+    # (a) flat -> flat
+    net2 = _net()
+    flat2 = FlatMixedPrecision(net2, lr=1e-2, max_norm=0.5)
+    missing, unexpected = flat2.load_module_state_dict(net2, sd, strict=True)
+    assert not missing and not unexpected
+    flat2.load_optimizer_state_dict(net2, osd)
+    la = [_flat_step(flat, net, x) for _ in range(2)]
+    lb = [_flat_step(flat2, net2, x) for _ in range(2)]
+    assert la == lb and torch.equal(flat.flat_w, flat2.flat_w)
+
+    # (b) flat -> plain model + per-parameter Adam (what the reference's loader does with this file)
+    ref = _net()
+    ref.load_state_dict(sd, strict=True)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    opt.load_state_dict(copy.deepcopy(osd))
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref(x).float().square().mean().backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+    net3 = _net()
+    flat3 = FlatMixedPrecision(net3, lr=1e-2, max_norm=0.5)
+    flat3.load_module_state_dict(net3, sd, strict=True)
+    flat3.load_optimizer_state_dict(net3, osd)
+    for _ in range(2):
+        _flat_step(flat3, net3, x)
+    for (k, v), q in zip(flat3.module_state_dict(net3).items(), ref.state_dict().values()):
+        if v.is_floating_point():
+            assert torch.allclose(v, q, atol=3e-3), k
+
+
+def test_full_precision_context_swaps_weights():
+    net = _net()
+    flat = FlatMixedPrecision(net, lr=1e-2)
+    assert net[0].weight.dtype == torch.bfloat16
+    with flat.full_precision():
+        assert net[0].weight.dtype == torch.float32
+        y = net(torch.randn(1, 3, 8, 8))          # plain fp32 forward, no autocast needed
+        assert y.dtype == torch.float32
+    assert net[0].weight.dtype == torch.bfloat16

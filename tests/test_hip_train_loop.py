@@ -55,9 +55,27 @@ def test_train_mono_one_epoch(tmp_path):
     ckpt = torch.load(tmp_path / "epoch_1.pth", weights_only=False)
     assert ckpt["meta"]["iter"] == 4 and "DepthDecoder.disp1.0.conv.weight" in ckpt["state_dict"]
     assert not torch.equal(ckpt["state_dict"]["DepthDecoder.disp1.0.conv.weight"], before)
+    # the flat mixed-precision store is the default in this mode; the file keeps the reference's layout: fp32 weights under
+    # the module's keys, per-parameter Adam state in model.parameters() order
+    flat = model._flat_store
+    assert model.DepthDecoder.disp1[0].conv.weight.dtype == torch.bfloat16 and flat.n_lp > 0
+    assert all(v.dtype == torch.float32 for v in ckpt["state_dict"].values() if v.is_floating_point())
+    n_train = len([p for p in model.parameters() if p.requires_grad])
+    assert len(ckpt["optimizer"]["state"]) == n_train and ckpt["optimizer"]["param_groups"][0]["params"] == list(range(n_train))
+    assert ckpt["optimizer"]["state"][0]["exp_avg"].shape == next(model.parameters()).shape
     logs = [f for f in os.listdir(tmp_path) if f.endswith(".log.json")]
     records = [json.loads(l) for l in open(tmp_path / logs[0])]
     train = [r for r in records if r["mode"] == "train" and "loss" in r]
     assert train and all(k in train[0] for k in ("loss", "('min_reconstruct_loss', 0)", "('smooth_loss', 3)", "lr"))
     assert all(r["loss"] == r["loss"] for r in train)            # finite
     assert any("abs_rel" in r for r in records)                  # the evaluation hook ran and published metrics
+    # resume into a fresh model: one more epoch from the file
+    cfg.resume_from = str(tmp_path / "epoch_1.pth")
+    cfg.total_epochs = 2
+    torch.manual_seed(1)
+    model2 = MONO.module_dict[cfg.model["name"]](cfg.model)
+    train_mono(model2, get_dataset(cfg.data, training=True), get_dataset(cfg.data, training=False), cfg,
+               distributed=False, validate=False)
+    ckpt2 = torch.load(tmp_path / "epoch_2.pth", weights_only=False)
+    assert ckpt2["meta"]["iter"] == 8 and float(ckpt2["optimizer"]["state"][0]["step"]) == 8.0
+    assert not torch.equal(ckpt2["state_dict"]["DepthDecoder.disp1.0.conv.weight"], ckpt["state_dict"]["DepthDecoder.disp1.0.conv.weight"])

@@ -19,6 +19,9 @@ the flat fp32 gradient/parameter buffers: gradients are gathered by batched conc
 all-reduced in a few large buckets, clipped and stepped by one single-tensor Adam.  That form costs the same as
 the plain step on one GPU and is what ``bench.py --gpus N`` (N > 1) uses between its two HIP graphs.
 """
+import collections
+import contextlib
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -58,6 +61,7 @@ class FlatMixedPrecision:
         self._pads = {}
         self.n_lp = n_lp
         self.offsets = offsets
+        self._offset_of = {id(p): off for p, off in zip(self.params, offsets)}
 
         def view(buf, p, off):
             return torch.as_strided(buf, p.size(), p.stride(), off)    # keeps channels_last strides
@@ -82,6 +86,106 @@ class FlatMixedPrecision:
         self.use_avg = dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         per = max(1, bucket_bytes // 4)
         self.buckets = [(s, min(s + per, n_all)) for s in range(0, n_all, per)]
+
+    # ------------------------------------------------------------------ checkpoint format
+    # A checkpoint written with the flat store is indistinguishable from one written without it (mmcv 0.4.4 layout,
+    # reference: mono/apis/trainer.py:163-189 through mmcv's CheckpointHook): 'state_dict' holds the fp32 MASTER value of
+    # every parameter under the module's own key, 'optimizer' the per-parameter Adam state in model.parameters() order.
+
+    def _master_view(self, p):
+        return torch.as_strided(self.flat_w, p.size(), p.stride(), self._offset_of[id(p)])
+
+    def module_state_dict(self, model):
+        """model.state_dict() with the fp32 master weights in place of the bf16 working copies."""
+        out = collections.OrderedDict()
+        params = dict(model.named_parameters())
+        for key, val in model.state_dict().items():
+            p = params.get(key)
+            out[key] = self._master_view(p).detach().clone() if p is not None and id(p) in self._offset_of else val
+        return out
+
+    def load_module_state_dict(self, model, state_dict, strict=False):
+        """Load fp32 weights into the master buffer (and refresh the bf16 working copy); buffers go through the module."""
+        params = dict(model.named_parameters())
+        rest, missing = {}, []
+        with torch.no_grad():
+            for key, val in state_dict.items():
+                p = params.get(key)
+                if p is not None and id(p) in self._offset_of:
+                    self._master_view(p).copy_(val.to(self.flat_w.device, torch.float32))
+                else:
+                    rest[key] = val
+            if self.n_lp:
+                self.flat_lp.copy_(self.flat_w[:self.n_lp])
+        for key, p in params.items():
+            if id(p) in self._offset_of and key not in state_dict:
+                missing.append(key)
+        own = dict(model.named_buffers())
+        own.update({k: p for k, p in params.items() if id(p) not in self._offset_of})
+        unexpected = [k for k in rest if k not in own]
+        with torch.no_grad():
+            for key, val in rest.items():
+                if key in own:
+                    own[key].copy_(val)
+        missing += [k for k in own if k not in state_dict]
+        if strict and (missing or unexpected):
+            raise RuntimeError("missing keys %s, unexpected keys %s" % (missing, unexpected))
+        return missing, unexpected
+
+    def optimizer_state_dict(self, model):
+        """torch.optim.Adam.state_dict() as a per-parameter optimiser over model.parameters() would write it."""
+        flat_state = self.optimizer.state.get(self.master, {})
+        group = self.optimizer.param_groups[0]
+        order = [p for p in model.parameters() if p.requires_grad]
+        state = {}
+        if flat_state:
+            for i, p in enumerate(order):
+                off = self._offset_of[id(p)]
+                view = lambda buf: torch.as_strided(buf, p.size(), p.stride(), off).detach().clone()   # noqa: E731
+                state[i] = {"step": flat_state["step"].detach().clone(), "exp_avg": view(flat_state["exp_avg"]),
+                            "exp_avg_sq": view(flat_state["exp_avg_sq"])}
+        pg = {k: v for k, v in group.items() if k != "params"}
+        pg["params"] = list(range(len(order)))
+        return {"state": state, "param_groups": [pg]}
+
+    def load_optimizer_state_dict(self, model, osd):
+        """Accepts the per-parameter format above (also what the reference's checkpoints hold)."""
+        order = [p for p in model.parameters() if p.requires_grad]
+        if len(osd["param_groups"]) != 1 or len(osd["param_groups"][0]["params"]) != len(order):
+            raise ValueError("optimizer state does not match the model: %d parameters expected" % len(order))
+        for k, v in osd["param_groups"][0].items():
+            if k != "params":
+                self.optimizer.param_groups[0][k] = v
+        if not osd["state"]:
+            return
+        dev = self.flat_w.device
+        st = self.optimizer.state[self.master]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=dev if self.optimizer.param_groups[0].get("capturable") else "cpu")
+            st["exp_avg"] = torch.zeros_like(self.flat_w)
+            st["exp_avg_sq"] = torch.zeros_like(self.flat_w)
+        with torch.no_grad():
+            for i, p in enumerate(order):
+                ps = osd["state"].get(i)
+                if ps is None:
+                    continue
+                off = self._offset_of[id(p)]
+                torch.as_strided(st["exp_avg"], p.size(), p.stride(), off).copy_(ps["exp_avg"].to(dev))
+                torch.as_strided(st["exp_avg_sq"], p.size(), p.stride(), off).copy_(ps["exp_avg_sq"].to(dev))
+                st["step"].copy_(torch.as_tensor(ps["step"], dtype=torch.float32))
+
+    @contextlib.contextmanager
+    def full_precision(self):
+        """Inside: the module computes with the fp32 master weights (validation runs in the reference's precision,
+        without autocast); outside: back on the bf16 working copy."""
+        saved = [(p, p.data) for p in self.lowp]
+        try:
+            for p in self.lowp:
+                p.data = self._master_view(p)
+            yield
+        finally:
+            for p, d in saved:
+                p.data = d
 
     def zero_grad(self):
         """Gradients are produced fresh by autograd each step (set_to_none) and gathered by collect()."""

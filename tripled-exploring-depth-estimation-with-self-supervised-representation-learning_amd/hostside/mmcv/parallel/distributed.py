@@ -154,7 +154,7 @@ class MMDistributedDataParallel(nn.Module):
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=False,
                  find_unused_parameters=False, bucket_cap_mb=64, process_group=None, overlap=True,
-                 engine_at_world_1=False, **kwargs):
+                 engine_at_world_1=False, gradient_engine=True, **kwargs):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("MMDistributedDataParallel needs an initialised process group (init_dist)")
@@ -168,7 +168,8 @@ class MMDistributedDataParallel(nn.Module):
         self.reducer = None
         # engine_at_world_1: run the bucket engine (and its collectives) in a one-rank group too -- the single-GPU
         # RCCL test of this code path; a real one-rank job skips it
-        if self.world > 1 or engine_at_world_1:
+        # gradient_engine=False: the owner exchanges gradients itself (the flat parameter store's own all-reduce)
+        if gradient_engine and (self.world > 1 or engine_at_world_1):
             self.reducer = GradientBuckets(list(module.parameters()), int(bucket_cap_mb * 1024 * 1024), process_group,
                                            overlap=overlap)
 

@@ -11,13 +11,24 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") else model
 
 
+def flat_store_of(model):
+    """The flat mixed-precision parameter store attached to a model by mono.apis.trainer (None without one): its
+    parameters are bf16 working copies, the checkpoint holds the fp32 masters (tripled_amd.flat_amp)."""
+    return getattr(_unwrap(model), "_flat_store", None)
+
+
 def load_state_dict(module, state_dict, strict=False, logger=None):
-    result = module.load_state_dict(state_dict, strict=strict)
+    flat = flat_store_of(module)
+    if flat is not None:
+        missing, unexpected = flat.load_module_state_dict(module, state_dict, strict=strict)
+    else:
+        result = module.load_state_dict(state_dict, strict=strict)
+        missing, unexpected = result.missing_keys, result.unexpected_keys
     problems = []
-    if result.unexpected_keys:
-        problems.append("unexpected key in source state_dict: {}".format(", ".join(result.unexpected_keys)))
-    if result.missing_keys:
-        problems.append("missing keys in source state_dict: {}".format(", ".join(result.missing_keys)))
+    if unexpected:
+        problems.append("unexpected key in source state_dict: {}".format(", ".join(unexpected)))
+    if missing:
+        problems.append("missing keys in source state_dict: {}".format(", ".join(missing)))
     if problems:
         msg = "The model and loaded state dict do not match exactly\n" + "\n".join(problems)
         if logger is not None:
@@ -54,7 +65,10 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
     from .. import __version__
     meta.update(mmcv_version=__version__, time=time.asctime())
     os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
-    checkpoint = {"meta": meta, "state_dict": weights_to_cpu(_unwrap(model).state_dict())}
+    module, flat = _unwrap(model), flat_store_of(model)
+    weights = flat.module_state_dict(module) if flat is not None else module.state_dict()
+    checkpoint = {"meta": meta, "state_dict": weights_to_cpu(weights)}
     if optimizer is not None:
-        checkpoint["optimizer"] = optimizer.state_dict()
+        # with the flat store the optimiser runs on ONE flat parameter; the file keeps the per-parameter layout
+        checkpoint["optimizer"] = flat.optimizer_state_dict(module) if flat is not None else optimizer.state_dict()
     torch.save(checkpoint, filename)

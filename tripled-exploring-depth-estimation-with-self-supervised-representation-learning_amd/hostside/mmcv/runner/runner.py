@@ -151,7 +151,12 @@ class Runner:
         self._epoch = ckpt["meta"]["epoch"]
         self._iter = ckpt["meta"]["iter"]
         if "optimizer" in ckpt and resume_optimizer and self.optimizer is not None:
-            self.optimizer.load_state_dict(ckpt["optimizer"])
+            from .checkpoint import _unwrap, flat_store_of
+            flat = flat_store_of(self.model)
+            if flat is not None:
+                flat.load_optimizer_state_dict(_unwrap(self.model), ckpt["optimizer"])
+            else:
+                self.optimizer.load_state_dict(ckpt["optimizer"])
         self.logger.info("resumed epoch %d, iter %d", self.epoch, self.iter)
 
     def run(self, data_loaders, workflow, max_epochs, **kwargs):

@@ -22,6 +22,9 @@ def _device():
 #                  BatchNorm / pool / pad / join kernels and MIOpen's MFMA implicit-GEMM kernels take
 #   strict_dispatch  False -- raise instead of warn when a HIP tensor falls back to an ATen composition
 #   fp8_conv1x1    False -- forward GEMM of the 1x1 convolutions on the fp8 MFMA path (mono.model.networks.set_fp8_conv1x1)
+#   flat_params    True with amp="bf16" on a HIP device, Adam without paramwise options -- the flat mixed-precision
+#                  parameter store (tripled_amd.flat_amp): one cast instead of ~500 per-weight casts per step, one
+#                  single-tensor Adam, gradient all-reduce on one flat buffer; checkpoints keep the reference's layout
 _MODE = {"autocast": None}
 
 
@@ -134,6 +137,26 @@ def build_optimizer(model, optimizer_cfg):
     return getattr(torch.optim, optimizer_cfg.pop("type"))(groups, **optimizer_cfg)
 
 
+def _use_flat_store(cfg, dev):
+    ocfg = cfg.optimizer
+    default = (dev.type == "cuda" and _MODE["autocast"] is torch.bfloat16 and ocfg.get("type") == "Adam"
+               and ocfg.get("paramwise_options") is None and not cfg.get("syncbn_foreign", False))
+    return bool(cfg.get("flat_params", default))
+
+
+def _build_flat_store(model, cfg):
+    """model's parameters move into the flat store; returns (store, optimiser hook).  The store hangs on the module as
+    ``_flat_store`` (not a sub-module): the checkpoint shim and the evaluation hooks look for it there."""
+    from tripled_amd.flat_amp import FlatMixedPrecision
+    from mono.core import FlatOptimizerHook
+    inner = model.module if hasattr(model, "module") else model
+    ocfg = dict(cfg.optimizer)
+    ocfg.pop("type")
+    flat = FlatMixedPrecision(inner, lowp=True, **ocfg)
+    inner._flat_store = flat
+    return flat, FlatOptimizerHook(flat, **cfg.optimizer_config)
+
+
 def _maybe_prefetch(loaders, cfg):
     """Overlap the host->device copy of batch t+1 with step t (cfg.device_prefetch, default on with a GPU)."""
     if torch.cuda.is_available() and cfg.get("device_prefetch", True):
@@ -160,13 +183,17 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
         from mono.model.networks import enable_sync_batchnorm
         enable_sync_batchnorm(model)
     model = configure_execution(model, cfg, dev)
+    use_flat = _use_flat_store(cfg, dev)
     model = MMDistributedDataParallel(model, find_unused_parameters=cfg.get("find_unused_parameters", False),
                                       device_ids=[dev.index] if dev.type == "cuda" else None,
-                                      broadcast_buffers=False)
-    optimizer = build_optimizer(model, cfg.optimizer)
+                                      broadcast_buffers=False, gradient_engine=not use_flat)
+    if use_flat:      # the store all-reduces its own flat gradient buffer; the wrapper only broadcasts the initial state
+        flat, opt_hook = _build_flat_store(model, cfg)
+        optimizer = flat.optimizer
+    else:
+        optimizer, opt_hook = build_optimizer(model, cfg.optimizer), DistOptimizerHook(**cfg.optimizer_config)
     runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
-    runner.register_training_hooks(cfg.lr_config, DistOptimizerHook(**cfg.optimizer_config),
-                                   cfg.checkpoint_config, cfg.log_config)
+    runner.register_training_hooks(cfg.lr_config, opt_hook, cfg.checkpoint_config, cfg.log_config)
     runner.register_hook(DistSamplerSeedHook())
     if validate:
         if "num_classes" in cfg:
@@ -178,9 +205,13 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
 def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False):
     data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, len(cfg.gpus), dist=False)]
     model = MMDataParallel(configure_execution(model, cfg, _device()), device_ids=list(range(len(cfg.gpus))))
-    optimizer = build_optimizer(model, cfg.optimizer)
+    if _use_flat_store(cfg, _device()):
+        flat, opt_hook = _build_flat_store(model, cfg)
+        optimizer = flat.optimizer
+    else:
+        optimizer, opt_hook = build_optimizer(model, cfg.optimizer), cfg.optimizer_config
     runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
-    runner.register_training_hooks(cfg.lr_config, cfg.optimizer_config, cfg.checkpoint_config, cfg.log_config)
+    runner.register_training_hooks(cfg.lr_config, opt_hook, cfg.checkpoint_config, cfg.log_config)
     if validate:
         if "num_classes" in cfg:
             raise NotImplementedError("segmentation evaluation is outside the depth training path")

@@ -5,6 +5,8 @@ definition; parity with cv2 itself is unpinned -- cv2 is not installed in the bu
 Per-rank results are merged with all_gather_object instead of pickle files + barriers."""
 import time
 
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -74,7 +76,10 @@ def _predict_one(model, sample):
         from mono.datasets import expand_device_batch
         expand_device_batch(batch)
     batch.pop("aug", None)
-    with torch.no_grad():
+    inner = model.module if hasattr(model, "module") else model
+    flat = getattr(inner, "_flat_store", None)
+    ctx = flat.full_precision() if flat is not None else contextlib.nullcontext()
+    with torch.no_grad(), ctx:        # (flat store: validate on the fp32 master weights, as the reference does)
         result = model(batch)
     scaled, _ = disp_to_depth(result[("disp", 0, 0)].float())
     gt = torch.as_tensor(sample["gt_depth"]).float().cpu().numpy()

@@ -70,3 +70,24 @@ class DistOptimizerHook(OptimizerHook):
         if self.grad_clip is not None:
             self.clip_grads(model.parameters())
         runner.optimizer.step()
+
+
+class FlatOptimizerHook(OptimizerHook):
+    """The iteration of DistOptimizerHook (zero_grad -> backward -> gradient average over the ranks -> clip -> step,
+    reference: dist_utils.py:54-60) on the flat mixed-precision parameter store (tripled_amd.flat_amp): gradients are
+    gathered into one flat fp32 buffer after backward, all-reduced there in a few large buckets, clipped with one norm
+    and stepped by one single-tensor Adam; the bf16 working copy of the convolution weights is refreshed by one cast."""
+
+    def __init__(self, flat, grad_clip=None, **_unused):
+        self.flat = flat
+        self.grad_clip = grad_clip
+        if grad_clip is not None and grad_clip.get("norm_type", 2) != 2:
+            raise ValueError("the flat store clips with the 2-norm")
+        self.flat.max_norm = grad_clip["max_norm"] if grad_clip else None
+
+    def after_train_iter(self, runner):
+        self.flat.zero_grad()
+        runner.outputs["loss"].backward()
+        self.flat.collect()
+        self.flat.allreduce()
+        self.flat.step()
