@@ -14,8 +14,9 @@ Two comparisons, tolerances stated:
    bitwise equal up to DepthEncoder.encoder.layer2.0.conv2 (the first stride-2 3x3 convolution at 128 channels) and
    differ from there on (tools/diag_misc.py: per-module comparison; none of the hand-written kernels differs) --
    measured 3 % (scale 0) to 50 % (scale 3) of the bf16 disparity pixels off by one ulp, single pixels by 3, loss
-   entries off by up to 1e-3 relative.  Every loss_dict entry must agree to 1e-5 + 3e-3 relative, the bf16
-   disparities to max 4 ulp and mean 0.5 ulp.  The parameters after the update
+   entries off by up to 3e-3 relative.  Every loss_dict entry must agree to 1e-5 + 1e-2 relative, the bf16
+   disparities to max 8 ulp and mean 1 ulp (2-3x the spread measured between two eager runs, so that the test does
+   not flake on the path's own nondeterminism).  The parameters after the update
    must agree with the eager run's next state to max |delta| <= 2.5 * lr (Adam's first updates are
    ~lr * sign(g): a noise-level gradient entry can flip a whole update; measured 1.3-1.6 lr) and mean
    |delta| <= 0.25 * lr (measured 0.03-0.06 lr).  The same bounds are asserted eager-vs-eager (noise floor:
@@ -42,7 +43,7 @@ K_STEPS = 3
 ULP = 2.0 ** -8
 
 
-def _build(cfg_name="cfg_kitti_tripleD.py", **over):
+def _build(cfg_name="cfg_kitti_tripleD.py", flat=False, **over):
     import tripled_amd  # noqa: F401
     from mmcv import Config
     from mono.datasets.synthetic import synthetic_batch
@@ -59,17 +60,21 @@ def _build(cfg_name="cfg_kitti_tripleD.py", **over):
     model.train()
     batch = synthetic_batch(m["imgs_per_gpu"], m["height"], m["width"], seed=1000, device=dev,
                             frame_ids=tuple(m["frame_ids"]))
-    return cfg, model, TrainStep(model, cfg, batch, torch.bfloat16)
+    return cfg, model, TrainStep(model, cfg, batch, torch.bfloat16, flat="lowp" if flat else False)
 
 
 def _snapshot(model, step):
+    masters = (step.flat.flat_w.clone(), step.flat.flat_lp.clone()) if step.flat is not None else None
     return (copy.deepcopy(model.state_dict()), copy.deepcopy(step.optimizer.state_dict()),
-            torch.cuda.get_rng_state())
+            torch.cuda.get_rng_state(), masters)
 
 
 def _restore(model, step, snap):
-    sd, osd, rng = snap
+    sd, osd, rng, masters = snap
     with torch.no_grad():
+        if masters is not None:                   # flat store: the fp32 masters and the bf16 working copy
+            step.flat.flat_w.copy_(masters[0])
+            step.flat.flat_lp.copy_(masters[1])
         cur = model.state_dict()
         for k, v in sd.items():
             cur[k].copy_(v)                       # in place: the graph holds these addresses
@@ -113,14 +118,18 @@ def _compare_tight(tag, i, ref, got, exact=False):
     if os.environ.get("TD_CALIBRATE"):
         return
     for k in l_r:
-        assert abs(l_r[k] - l_g[k]) < 1e-5 + 3e-3 * abs(l_r[k]), (tag, i, k, l_r[k], l_g[k])
+        assert abs(l_r[k] - l_g[k]) < 1e-5 + 1e-2 * abs(l_r[k]), (tag, i, k, l_r[k], l_g[k])
     for s, (a, b) in enumerate(zip(d_r, d_g)):
         d = (a - b).abs()
-        assert float(d.max()) <= 4 * ULP + 1e-7, (tag, i, s, float(d.max()))
+        assert float(d.max()) <= 8 * ULP + 1e-7, (tag, i, s, float(d.max()))
         assert float(d.mean()) < 1.0 * ULP, (tag, i, s, float(d.mean()) / ULP)
 
 
-def _param_delta(model, sd):
+def _param_delta(model, snap, step):
+    if step.flat is not None:                     # compare the fp32 masters (the module holds bf16 working copies)
+        d = (step.flat.flat_w - snap[3][0]).abs()
+        return float(d.max()), float(d.mean())
+    sd = snap[0]
     cur = model.state_dict()
     mx, tot, n = 0.0, 0.0, 0
     for k, p in model.named_parameters():
@@ -137,21 +146,22 @@ def _param_delta(model, sd):
 SMALL = dict(depth_num_layers=18, pose_num_layers=18, extractor_num_layers=18, imgs_per_gpu=4, height=96, width=320)
 
 
-@pytest.mark.parametrize("capture,deterministic", [("side", True), ("default", True), ("side", False)])
-def test_graph_replay_matches_eager_c2(capture, deterministic):
+# last case = exactly what bench.py runs by default: C2 size, single-stream capture, flat mixed-precision parameter store
+@pytest.mark.parametrize("capture,deterministic,flat", [("side", True, False), ("default", True, True), ("side", False, True)])
+def test_graph_replay_matches_eager_c2(capture, deterministic, flat):
     from tripled_amd import dispatch
     from tripled_amd.step import capture_step, warm_up
     assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
     prev = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = deterministic      # MIOpen: only solvers without order-dependent accumulation
     try:
-        _run(capture, deterministic, dispatch, capture_step, warm_up)
+        _run(capture, deterministic, flat, dispatch, capture_step, warm_up)
     finally:
         torch.backends.cudnn.deterministic = prev
 
 
-def _run(capture, deterministic, dispatch, capture_step, warm_up):
-    cfg, model, step = _build(**(SMALL if deterministic else {}))
+def _run(capture, deterministic, flat, dispatch, capture_step, warm_up):
+    cfg, model, step = _build(flat=flat, **(SMALL if deterministic else {}))
     lr = cfg.optimizer["lr"]
     dispatch.reset()
     side = torch.cuda.Stream()
@@ -187,7 +197,7 @@ def _run(capture, deterministic, dispatch, capture_step, warm_up):
         _restore(model, step, snaps[i])
         graphed()
         _compare_tight(capture, i, eager[i], _record(step), exact=deterministic)
-        mx, mean = _param_delta(model, snaps[i + 1][0])
+        mx, mean = _param_delta(model, snaps[i + 1], step)
         print("[%s same-state %d] parameters after the update vs eager: max %.2f lr, mean %.4f lr" % (capture, i, mx / lr, mean / lr))
         assert mx <= 2.5 * lr and mean <= 0.25 * lr, (capture, i, mx / lr, mean / lr)
 
