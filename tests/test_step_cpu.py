@@ -1,0 +1,58 @@
+"""tripled_amd.step on the host (oracle loss backend): the iteration bench.py / the tests share, and its health gate."""
+import math
+
+import pytest
+import torch
+
+import tripled_amd  # noqa: F401
+from mmcv import ConfigDict
+from mono.datasets import synthetic_batch
+from mono.model import MONO
+from oracle.backend import OracleLossBackend
+from tripled_amd.step import NonFiniteLossError, TrainStep
+
+
+def _step():
+    B, H, W = 1, 64, 128
+    opt = ConfigDict(name="mono_fm", depth_num_layers=18, pose_num_layers=18, extractor_num_layers=18, frame_ids=[0, -1, 1],
+                     imgs_per_gpu=B, height=H, width=W, scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0,
+                     depth_pretrained_path=None, pose_pretrained_path=None, extractor_pretrained_path=None, automask=True,
+                     disp_norm=True, perception_weight=1e-3, smoothness_weight=1e-3)
+    cfg = ConfigDict(model=opt, optimizer=dict(type="Adam", lr=1e-4, weight_decay=0),
+                     optimizer_config=dict(grad_clip=dict(max_norm=35, norm_type=2)))
+    torch.manual_seed(0)
+    model = MONO.module_dict["mono_fm"](opt)
+    model.set_loss_backend(OracleLossBackend())
+    model.train()
+    return model, TrainStep(model, cfg, synthetic_batch(B, H, W, seed=1, with_mask=False), None)
+
+
+def test_train_step_runs_and_reports():
+    model, step = _step()
+    before = model.DepthDecoder.disp1[0].conv.weight.detach().clone()
+    loss = step()
+    assert math.isfinite(float(loss)) and set(map(str, step.losses)) >= {"('min_reconstruct_loss', 0)", "('smooth_loss', 3)"}
+    assert abs(float(sum(step.losses.values())) - float(loss)) < 1e-6
+    assert ("disp", 0, 0) in step.outputs and float(step.grad_norm) > 0
+    assert not torch.equal(model.DepthDecoder.disp1[0].conv.weight, before)
+    assert step.check_finite() == float(loss)
+
+
+def test_health_gate_names_the_broken_piece():
+    model, step = _step()
+    step()
+    with torch.no_grad():
+        model.PoseDecoder.conv3.weight[0, 0, 0, 0] = float("nan")
+    with pytest.raises(NonFiniteLossError, match="PoseDecoder.conv3.weight"):
+        step.check_finite("poisoned")
+    step.loss = torch.tensor(float("nan"))
+    step.losses[("smooth_loss", 0)] = torch.tensor(float("inf"))
+    with pytest.raises(NonFiniteLossError, match="smooth_loss"):
+        step.check_finite("a non-finite loss")
+
+
+def test_only_adam_configs_are_accepted():
+    model, step = _step()
+    cfg = ConfigDict(model=model.opt, optimizer=dict(type="SGD", lr=1e-2), optimizer_config=dict(grad_clip=None))
+    with pytest.raises(ValueError):
+        TrainStep(model, cfg, step.batch, None)
