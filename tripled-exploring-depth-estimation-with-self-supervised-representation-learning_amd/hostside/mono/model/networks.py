@@ -553,6 +553,21 @@ class _ConvImmediate(torch.autograd.Function):
         return gx, gw, (gb if ctx.has_bias else None)
 
 
+class _KeepChannels(torch.autograd.Function):
+    """y[:, :c] of a channel-padded convolution output.  Forward: the view itself (nothing is copied).  Backward: ONE
+    zero-padding pass; autograd's slice backward is a zero-fill of the full tensor plus a strided copy into it
+    (two passes over up to 12 x 8 x 192 x 640 per head, twelve heads per step)."""
+
+    @staticmethod
+    def forward(ctx, y, c):
+        ctx.pad = y.shape[1] - c
+        return y.narrow(1, 0, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return F.pad(g, (0, 0, 0, 0, 0, ctx.pad)), None
+
+
 def _conv2d_guarded(x, w, b):
     """F.conv2d, except for the narrow (<= 16 channels) layers on inputs wider than 1024 columns: see _ConvImmediate."""
     if x.is_cuda and x.shape[1] <= 16 and w.shape[0] <= 16 and x.shape[3] > 1024 and torch.backends.cudnn.benchmark:
@@ -609,7 +624,7 @@ class Conv3x3(nn.Module):
         if b is not None and cout_p != cout:
             b = F.pad(b, (0, cout_p - cout))
         y = _conv2d_guarded(self._pad_input(x), w, b)
-        return y[:, :cout] if cout_p != cout else y
+        return _KeepChannels.apply(y, cout) if cout_p != cout else y
 
 
     def forward_up(self, x):
@@ -627,7 +642,7 @@ class Conv3x3(nn.Module):
                 w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
                 b = F.pad(b, (0, cout_p - cout)) if b is not None else None
             y = _conv2d_guarded(_ops().up2_reflpad1(x), w, b)
-            return y[:, :cout] if cout_p != cout else y
+            return _KeepChannels.apply(y, cout) if cout_p != cout else y
         _fell_back("Conv3x3.forward_up", x)
         return self.forward(upsample(x))
 
