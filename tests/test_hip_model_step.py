@@ -141,3 +141,51 @@ def test_bf16_channels_last_forward_vs_fp32_cpu_oracle():
         stats.append((float(d.max()), float(d.mean())))
         assert float(d.max()) < 8e-3 and float(d.mean()) < 2e-3, (s, float(d.max()), float(d.mean()))
     print("bf16 vs fp32 oracle: disp (max, mean) per scale %s; worst loss entry at %.2f of its tolerance" % (stats, worst))
+
+
+def test_stereo_plus_temporal_frames_match_cpu_oracle():
+    """frame_ids = [0, -1, 1, 's'] (the reference's stereo + monocular setting: automask and disp_norm off,
+    config/cfg_kitti_*.py `STEREO`): three source frames, the stereo one warped with inputs["stereo_T"]; the GPU
+    model (HIP kernels, NS = 3) against the same weights on the CPU with the oracle loss path."""
+    import tripled_amd  # noqa: F401
+    from mono.datasets import synthetic_batch
+    from mono.model import MONO
+    from mono.model.hotpath import HipLossBackend
+    from oracle.backend import OracleLossBackend
+    name = "mono_fm_joint_inpaint_disentangle"
+    B, H, W = 2, 96, 160
+    opt = _opt(name, B, H, W)
+    opt["frame_ids"] = [0, -1, 1, "s"]
+    opt["automask"] = False
+    opt["disp_norm"] = False
+    torch.manual_seed(13)
+    cpu = MONO.module_dict[name](opt)
+    gpu = copy.deepcopy(cpu).cuda()
+    cpu.set_loss_backend(OracleLossBackend())
+    gpu.set_loss_backend(HipLossBackend())
+    for m in (cpu, gpu):
+        m.train()
+        m.DepthDecoder.do.eval()
+    batch = synthetic_batch(B, H, W, seed=5, frame_ids=(0, -1, 1, "s"))
+    stereo_T = torch.eye(4).repeat(B, 1, 1)
+    stereo_T[:, 0, 3] = 0.1
+    batch["stereo_T"] = stereo_T
+    out_c, loss_c = cpu(dict(batch))
+    out_g, loss_g = gpu({k: v.cuda() for k, v in batch.items()})
+    assert list(map(str, loss_c)) == list(map(str, loss_g))
+    for k in loss_c:
+        x, y = float(loss_g[k].mean()), float(loss_c[k].mean())
+        assert abs(x - y) < 2e-6 + 2e-3 * abs(y), (k, x, y)
+    for s in range(4):
+        assert out_g[("color", "s", s)].shape == (B, 3, H, W)
+        assert int(out_g[("min_index", s)].max()) <= 2          # three warped candidates, no identity terms
+    sum(v.mean() for v in loss_g.values()).backward()
+    sum(v.mean() for v in loss_c.values()).backward()
+    pc = dict(cpu.named_parameters())
+    num = den = 0.0
+    for n, p in gpu.named_parameters():
+        if pc[n].grad is None:
+            continue
+        num += float((p.grad.cpu().double() - pc[n].grad.double()).pow(2).sum())
+        den += float(pc[n].grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 < 3e-2

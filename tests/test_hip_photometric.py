@@ -202,3 +202,55 @@ def test_full_size_backward_matches_oracle(ops):
     assert abs(float(loss) - ref_loss) < 2e-6
     assert rel_err(d.grad, d_ref) < 2e-3
     assert rel_err(P.grad, P_ref) < 2e-3
+
+
+@pytest.mark.parametrize("n_src", [1, 3, 4])
+@pytest.mark.parametrize("automask", [True, False])
+def test_other_source_counts(ops, n_src, automask):
+    """frame_ids with one source ([0, 's']), three ([0, -1, 1, 's']) and the ABI's maximum of four: forward (warps, exact
+    arg-min, loss) and backward (d disp, d P) of the template instantiations the two-source tests never reach."""
+    B, H, W, hs, ws = 2, 40, 72, 20, 36
+    g = torch.Generator().manual_seed(20 + n_src)
+    base = smooth_image(g, B, 3, H + 8, W + 8)
+    tgt = base[:, :, 4:4 + H, 4:4 + W].contiguous()
+    srcs = [(base[:, :, 4 + (i % 2):4 + (i % 2) + H, 3 + i:3 + i + W] + 0.01 * torch.randn(B, 3, H, W, generator=g)).clamp(0, 1).contiguous()
+            for i in range(n_src)]
+    K, invK = kitti_K(B, H, W)
+    Ts = []
+    for i in range(n_src):
+        axis = 0.01 * torch.randn(B, 1, 3, generator=g)
+        t = 0.15 * torch.randn(B, 1, 3, generator=g)
+        Ts.append(geometry.transformation_from_parameters(axis, t[:, 0], invert=(i % 2 == 0)))
+    disp = (0.05 + 0.9 * smooth_image(g, B, 1, hs, ws)).contiguous()
+    noise = torch.randn(n_src, B, H, W, generator=g)
+    cs = [s.cuda() for s in srcs]
+    idl = ops.photo_identity(tgt.cuda(), cs) if automask else None
+    d = disp.cuda().requires_grad_(True)
+    P = _P(K, Ts).cuda().requires_grad_(True)
+    loss, argmin, warped = ops.photometric_scale_loss(d, P, tgt.cuda(), cs, invK.cuda(), idl,
+                                                      noise.cuda() if automask else None, 0.1, 100.0, 4, keep_warped=True)
+    nz = [noise[i].unsqueeze(1) for i in range(n_src)] if automask else None
+    ref_loss, ref_idx, ref_warped = photometric.photometric_scale_loss(tgt, srcs, disp, K, invK, Ts, nz, 0.1, 100.0,
+                                                                       automask=automask, n_scales=4)
+    for i in range(n_src):
+        assert float((warped[i].cpu() - ref_warped[i]).abs().max()) < 1e-4
+    _, _, stack = photometric.min_reprojection(tgt, srcs, ref_warped, nz, automask)
+    assert stack.shape[1] == (2 * n_src if automask else n_src)
+    assert_argmin_parity(argmin, ref_idx, stack)
+    assert abs(float(loss) - float(ref_loss)) < 2e-6 + 1e-5 * abs(float(ref_loss))
+    (loss * 3.0).backward()
+    dr = disp.clone().requires_grad_(True)
+    Pr = _P(K, Ts).requires_grad_(True)
+    rw = []
+    for i in range(n_src):
+        up = geometry.upsample_bilinear(dr, H, W)
+        _, depth = geometry.disp_to_depth(up, 0.1, 100.0)
+        cam = torch.matmul(Pr[i], geometry.backproject(depth, invK))
+        uv = cam[:, :2] / (cam[:, 2:3] + 1e-7)
+        gx = (uv[:, 0].reshape(B, H, W) / (W - 1) - 0.5) * 2
+        gy = (uv[:, 1].reshape(B, H, W) / (H - 1) - 0.5) * 2
+        rw.append(geometry.grid_sample_border(srcs[i], torch.stack([gx, gy], -1)))
+    vals, _, _ = photometric.min_reprojection(tgt, srcs, rw, nz, automask, forced_index=argmin.cpu().long())
+    (vals.mean() / 4 * 3.0).backward()
+    assert rel_err(d.grad, dr.grad) < 2e-3
+    assert rel_err(P.grad, Pr.grad) < 2e-3
