@@ -98,7 +98,12 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
     float dv[4], dv_n[4], ul0, ul1, ul0_n, ul1_n;
     Tap tap = {};
     TapVals tv[3] = {};
-    float yq[3], depth_q = 0.f, cf_n[9], m_n, mq_n;
+    float depth_q = 0.f;
+    // field pipeline, THREE rows deep (the backward is memory-latency bound: SQ_WAIT_ANY 47 % with two): slot A holds
+    // coefficient row k (loaded two iterations ago), slot B row k+1 (loaded in the previous iteration); the raw arg-min
+    // bytes travel with them and the masks are formed at consumption, so no load is waited for when it is issued
+    float cfA[9], cfB[9], yqA[3], yqB[3];
+    unsigned amA = 0, amB = 0, aqA = 0, aqB = 0;
     auto issue_disp = [&](int q, float* d4, float& l0, float& l1) {        // gradient row q (clamped)
       const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
       const UpIdx uy = up_index(qc, ratio_y, a.hs);
@@ -107,24 +112,26 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
       d4[2] = dispb[o1 + (unsigned)ux.i0]; d4[3] = dispb[o1 + (unsigned)ux.i1];
       l0 = uy.l0; l1 = uy.l1;
     };
-    auto issue_row = [&](int k, const float* d4, float l0, float l1) {
-      const int r = y0 - 1 + k;                      // coefficient row
-      const bool inside = r >= 0 && r < H && col_in;
+    auto issue_field = [&](int k, float* cf9, float* yq3, unsigned& am, unsigned& aq) {
+      const int r = y0 - 1 + k;                      // coefficient row; its gradient row is q = r - 1
       const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
       const unsigned offc = (unsigned)(rc * W + xc);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) cf_n[i] = cfb[i * plane + offc];
-      m_n = (inside && (int)amb[offc] == sel) ? g_ssim : 0.f;
-      // warp of gradient row q = r - 1
+      for (int i = 0; i < 9; ++i) cf9[i] = cfb[i * plane + offc];
+      am = amb[offc];
       const int q = r - 1;
       const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
       const unsigned offq = (unsigned)(qc * W + xc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) yq[c] = tgtb[c * plane + offq];
-      mq_n = (q >= 0 && q < H && (int)amb[offq] == sel) ? g_l1 : 0.f;
+      for (int c = 0; c < 3; ++c) yq3[c] = tgtb[c * plane + offq];
+      aq = amb[offq];
+    };
+    auto issue_warp = [&](int k, const float* d4, float l0, float l1) {
       // rows k = 0, 1 only feed the vertical window of the coefficient sums: their warp (q above the chunk) is
       // never consumed, so the projection and the 12 gathers are skipped (k is wave-uniform: a scalar branch)
       if (k >= 2) {
+        const int q = y0 - 2 + k;
+        const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
         const float dd = l0 * (ux.l0 * d4[0] + ux.l1 * d4[1]) + l1 * (ux.l0 * d4[2] + ux.l1 * d4[3]);
         depth_q = fast_rcp(a.min_disp + a.disp_range * dd);
         const float fy = (float)qc;
@@ -137,17 +144,24 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
     };
     issue_disp(y0 - 2, dv, ul0, ul1);                // q of k = 0
     issue_disp(y0 - 1, dv_n, ul0_n, ul1_n);          // q of k = 1
-    issue_row(0, dv, ul0, ul1);
+    issue_field(0, cfA, yqA, amA, aqA);
+    issue_field(1, cfB, yqB, amB, aqB);
+    issue_warp(0, dv, ul0, ul1);
 
 #pragma unroll 1
     for (int k = 0; k < NK; ++k) {
       // ---- consume: coefficient row r, warp of row q = r-1 ----
+      const int r_k = y0 - 1 + k;
+      const bool inside = r_k >= 0 && r_k < H && col_in;
+      const float m_k = (inside && (int)amA == sel) ? g_ssim : 0.f;
+      const int q_k = r_k - 1;
+      const float ml1 = (q_k >= 0 && q_k < H && (int)aqA == sel) ? g_l1 : 0.f;
       float cf[9], xq[3], yv[3], dxi[3], dyi[3];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) cf[i] = cf_n[i] * m_n;
+      for (int i = 0; i < 9; ++i) cf[i] = cfA[i] * m_k;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { xq[c] = 0.f; yv[c] = yq[c]; dxi[c] = 0.f; dyi[c] = 0.f; }
-      if (k >= 2) {                                   // rows above the chunk have no warp (see issue_row)
+      for (int c = 0; c < 3; ++c) { xq[c] = 0.f; yv[c] = yqA[c]; dxi[c] = 0.f; dyi[c] = 0.f; }
+      if (k >= 2) {                                   // rows above the chunk have no warp (see issue_warp)
         const float ex = (float)tap.x0 + 1.f - tap.ix, wx = tap.ix - (float)tap.x0;
         const float ey = (float)tap.y0 + 1.f - tap.iy, wy = tap.iy - (float)tap.y0;
         const float mx = tap.gmx * sx_scale, my = tap.gmy * sy_scale;
@@ -162,13 +176,19 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
           dyi[c] = (-vnw * ex - vne * wx + vsw * ex + vse * wx) * my;     // d x_c / d v
         }
       }
-      const float dq = depth_q, ml1 = mq_n;
-      // ---- refill the pipeline (rows beyond the chunk are clamped duplicates, never consumed) ----
+      const float dq = depth_q;
+      // ---- advance the pipelines (rows beyond the chunk are clamped duplicates, never consumed) ----
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cfA[i] = cfB[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) yqA[c] = yqB[c];
+      amA = amB; aqA = aqB;
+      issue_field(k + 2, cfB, yqB, amB, aqB);
 #pragma unroll
       for (int i = 0; i < 4; ++i) dv[i] = dv_n[i];
       ul0 = ul0_n; ul1 = ul1_n;
       issue_disp(y0 + k, dv_n, ul0_n, ul1_n);        // q of k + 2
-      issue_row(k + 1, dv, ul0, ul1);
+      issue_warp(k + 1, dv, ul0, ul1);
 
       // ---- box filter of the coefficient field -> gradient w.r.t. the warped pixel of row q ----
       const int q = y0 - 2 + k;
