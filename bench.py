@@ -70,6 +70,9 @@ def parse():
     p.add_argument("--no-flat", action="store_true",
                    help="autocast + per-parameter fused Adam instead of the flat bf16/fp32 parameter store (tripled_amd/flat_amp.py; "
                         "the store is the trainer's default with amp='bf16', mono/apis/trainer.py)")
+    p.add_argument("--frames", default="coherent", choices=["coherent", "iid"],
+                   help="coherent: the three frames are shifted crops of one canvas (like driving data; the headline input); "
+                        "iid: independent uniform noise per frame (the adversarial case of SURVEY.md section 8d)")
     p.add_argument("--no-roofline", action="store_true", help="skip the isolated kernel timing (profiling runs)")
     p.add_argument("--fp8", action="store_true", help="forward GEMM of the eligible 1x1 convolutions on the fp8 MFMA path "
                                                       "(BASELINE config 5; off by default: measured slower at these sizes, DESIGN.md)")
@@ -290,7 +293,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]))
+    batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]),
+                            coherent=args.frames == "coherent")
     side = torch.cuda.Stream()
     cap = side if CAPTURE_STREAM == "side" else None
     dispatch.reset()
@@ -488,7 +492,7 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 convs (MFMA) + f32 loss kernels" + (", fp8 forward GEMM of the 1x1 convs" if args.fp8 else ""))
             if dtype is not None else "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.frames == "coherent" else "synthetic (i.i.d. noise frames)",
             "config": {"workload": "%s %dx%d bs=%d/GPU (%s), fwd+bwd+clip+Adam" % (
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
                 "parallelism": "dp%d" % world, "hip_graph": graphed,

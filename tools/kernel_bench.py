@@ -77,6 +77,14 @@ def main():
     def want(k):
         return only is None or k in only
 
+    if only is not None and "hbm" in only:
+        # what a plain device-to-device copy reaches on this box, next to the 8 TB/s the rooflines are priced against
+        # (SURVEY.md section 8d); 1 GiB each way, far past the Infinity Cache
+        n = 1 << 30
+        a8, b8 = torch.empty(n, device=dev, dtype=torch.uint8), torch.empty(n, device=dev, dtype=torch.uint8)
+        us = timeit(lambda: b8.copy_(a8), args.iters)
+        print(json.dumps({"d2d_copy_us": us, "bytes_moved": 2 * n, "GB_per_s": 2 * n / us / 1e3}))
+        return
     if only is not None and "calib" in only:
         # calibration of the FETCH_SIZE / WRITE_SIZE counters for THIS access width: td_l1map_fwd on one-channel tensors
         # streams 2 x 4 B/pixel in and 4 B/pixel out, one dword per lane, far past the 256 MiB Infinity Cache

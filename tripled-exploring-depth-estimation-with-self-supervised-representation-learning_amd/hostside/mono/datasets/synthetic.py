@@ -27,7 +27,9 @@ def _smooth_canvas(g, h, w):
 
 
 def make_sample(seed, height, width, frame_ids=(0, -1, 1), erase_shape=(16, 16), erase_count=16, max_shift=4,
-                with_mask=True, wire="float32", augment=False):
+                with_mask=True, wire="float32", augment=False, coherent=True):
+    """coherent=False: every frame is independent U[0,1) noise -- the adversarial input of SURVEY.md section 8d
+    (no frame explains another, so the arg-min and the bilinear taps see uncorrelated values)."""
     g = torch.Generator().manual_seed(int(seed))
     canvas = _smooth_canvas(g, height + 2 * max_shift, width + 2 * max_shift)
     sample = {}
@@ -37,7 +39,10 @@ def make_sample(seed, height, width, frame_ids=(0, -1, 1), erase_shape=(16, 16),
         else:
             dy = int(torch.randint(0, 2 * max_shift + 1, (1,), generator=g))
             dx = int(torch.randint(0, 2 * max_shift + 1, (1,), generator=g))
-        img = canvas[:, dy:dy + height, dx:dx + width].contiguous()
+        if coherent:
+            img = canvas[:, dy:dy + height, dx:dx + width].contiguous()
+        else:
+            img = torch.rand(3, height, width, generator=g)
         if wire == "uint8":      # the byte wire format of the KITTI loader (kitti_dataset.py), expanded on the device
             sample[("color_u8", f)] = (img * 255.0).round().clamp_(0, 255).to(torch.uint8)
             continue
