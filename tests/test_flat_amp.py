@@ -42,7 +42,7 @@ def test_flat_store_matches_autocast_adam():
     for p, off in zip(flat.params, flat.offsets):      # flat order: convolution parameters first, then the fp32 ones
         master = torch.as_strided(flat.flat_w, p.size(), p.stride(), off)
         assert torch.allclose(master, twin[id(p)].detach(), atol=3e-3), p.shape
-        if p.dtype == torch.bfloat16:   # (TD_FLAT_LOWP=0 keeps every parameter fp32)
+        if p.dtype == torch.bfloat16:   # (lowp=False keeps every parameter fp32)
             assert torch.equal(p.detach(), master.to(torch.bfloat16))
         assert off % 8 == 0
 

@@ -26,9 +26,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-
-import os
-ALIGN = int(os.environ.get('TD_FLAT_ALIGN', '8'))      # elements: 16 B in bf16, 32 B in fp32
+ALIGN = 8      # elements: 16 B in bf16, 32 B in fp32
 
 
 class FlatMixedPrecision:
@@ -38,7 +36,7 @@ class FlatMixedPrecision:
         dev = params[0].device
         lowp_ids = set()
         for m in model.modules():
-            if isinstance(m, nn.Conv2d) and (os.environ.get('TD_FLAT_LOWP', '1') == '1' if lowp is None else lowp):
+            if isinstance(m, nn.Conv2d) and (lowp is None or lowp):
                 for p in m.parameters(recurse=False):
                     if p.requires_grad:
                         lowp_ids.add(id(p))

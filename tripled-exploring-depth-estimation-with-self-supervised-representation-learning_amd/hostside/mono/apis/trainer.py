@@ -139,8 +139,10 @@ def build_optimizer(model, optimizer_cfg):
 
 def _use_flat_store(cfg, dev):
     ocfg = cfg.optimizer
+    # weight_decay: a parameter no gradient reaches has a zero slot in the flat gradient buffer, which Adam would still
+    # decay; the per-parameter optimiser skips it (grad None), so configs with decay keep the per-parameter path
     default = (dev.type == "cuda" and _MODE["autocast"] is torch.bfloat16 and ocfg.get("type") == "Adam"
-               and ocfg.get("paramwise_options") is None and not cfg.get("syncbn_foreign", False))
+               and ocfg.get("paramwise_options") is None and not ocfg.get("weight_decay", 0))
     return bool(cfg.get("flat_params", default))
 
 
