@@ -1,0 +1,110 @@
+"""train.py: command line -> cfg (CPU) and a full `train.main` run on synthetic triplets (GPU).
+The CLI surface is the reference's (train.py:36-124): --config --work_dir --resume_from --gpus --seed --launcher."""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TINY_CFG = '''
+H, W, B = 96, 160, 2
+data = dict(name="synthetic", split="exp", height=H, width=W, frame_ids=[0, -1, 1], in_path=None, gt_depth_path=None,
+            png=True, stereo_scale=False, erase_shape=[8, 8], erase_count=4, synthetic_length=4, synthetic_val_length=2)
+model = dict(name="mono_fm_joint_inpaint_disentangle", depth_num_layers=18, pose_num_layers=18, extractor_num_layers=18,
+             frame_ids=[0, -1, 1], imgs_per_gpu=B, height=H, width=W, scales=[0, 1, 2, 3], min_depth=0.1, max_depth=100.0,
+             depth_pretrained_path=None, pose_pretrained_path=None, extractor_pretrained_path=None, automask=True,
+             disp_norm=True, dis=1e-3, cvt=1e-3, perception_weight=1e-3, smoothness_weight=1e-3, auto_res_weight=5e-3,
+             disentangle_layers=[False, False, False, False, True], skip_connection_multiplier=1, depth_skip_type=None,
+             color_skip_type=None, color_skip_layers=[False] * 4, depth_use_shuffle=False,
+             depth_disentangle_type="use_half", freeze_extractor=False)
+resume_from = None
+finetune = None
+load_from = None
+total_epochs = 1
+imgs_per_gpu = B
+learning_rate = 1e-4
+workers_per_gpu = 0
+validate = False
+optimizer = dict(type="Adam", lr=learning_rate, weight_decay=0)
+optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))
+lr_config = dict(policy="step", warmup="linear", warmup_iters=1, warmup_ratio=1.0 / 3, step=[10], gamma=0.5)
+checkpoint_config = dict(interval=1)
+log_config = dict(interval=1, hooks=[dict(type="TextLoggerHook")])
+dist_params = dict(backend="nccl")
+log_level = "INFO"
+workflow = [("train", 1)]
+syncbn = False
+cudnn_benchmark = False
+amp = "bf16"
+channels_last = True
+strict_dispatch = True
+'''
+
+
+def _train_module():
+    spec = importlib.util.spec_from_file_location("td_train_cli", os.path.join(ROOT, "train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _write_cfg(tmp_path):
+    path = tmp_path / "cfg_tiny.py"
+    path.write_text(TINY_CFG)
+    return str(path)
+
+
+def test_command_line_to_cfg(tmp_path):
+    train = _train_module()
+    cfg_path = _write_cfg(tmp_path)
+    args, cfg = train.read_job(["--config", cfg_path, "--work_dir", str(tmp_path / "w"), "--gpus", "0,1",
+                                "--resume_from", "some.pth", "--launcher", "none", "--seed", "7"])
+    assert (args.launcher, args.seed) == ("none", 7)
+    assert cfg.work_dir == str(tmp_path / "w") and cfg.gpus == [0, 1] and cfg.resume_from == "some.pth"
+    assert cfg.model["name"] == "mono_fm_joint_inpaint_disentangle" and cfg.optimizer["type"] == "Adam"
+    # defaults: the shipped tripleD config, the torch.distributed.run launcher, the reference's seed
+    args, cfg = train.read_job([])
+    assert args.launcher == "pytorch" and args.seed == 1024 and cfg.resume_from is None
+    assert os.path.basename(args.config) == "cfg_kitti_tripleD.py" and cfg.model["name"] == "mono_fm_joint_inpaint_disentangle"
+    with pytest.raises(SystemExit):        # launchers this build does not start
+        train.read_job(["--launcher", "slurm"])
+
+
+def test_finetune_weights_are_loaded_safely(tmp_path):
+    import tripled_amd  # noqa: F401
+    from mmcv import Config
+    train = _train_module()
+    net = torch.nn.Sequential(torch.nn.Linear(3, 2))
+    ref = {k: torch.full_like(v, 0.25) for k, v in net.state_dict().items()}
+    torch.save({"state_dict": ref, "meta": {"epoch": 3}}, tmp_path / "ft.pth")
+    train.initial_weights(net, Config(dict(resume_from=None, finetune=str(tmp_path / "ft.pth"))))
+    assert all(torch.equal(v, ref[k]) for k, v in net.state_dict().items())
+    # a file that needs the unpickler to execute code is refused (weights_only load)
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save({"state_dict": ref, "x": Evil()}, tmp_path / "bad.pth")
+    with pytest.raises(Exception):
+        train.initial_weights(net, Config(dict(resume_from=None, finetune=str(tmp_path / "bad.pth"))))
+
+
+@pytest.mark.gpu
+def test_train_main_single_process(tmp_path):
+    """`python train.py --launcher none` end to end: config file -> model -> two iterations -> checkpoint + config copy."""
+    from tripled_amd import dispatch
+    train = _train_module()
+    cfg_path = _write_cfg(tmp_path)
+    work = tmp_path / "work"
+    dispatch.reset()
+    try:
+        train.main(["--config", cfg_path, "--work_dir", str(work), "--launcher", "none", "--seed", "3"])
+    finally:
+        dispatch.set_strict(False)
+    assert sum(dispatch.fallbacks.values()) == 0, dict(dispatch.fallbacks)
+    assert dispatch.hip_calls["td_photo_fwd"] > 0
+    assert os.path.exists(work / "cfg_tiny.py") and os.path.exists(work / "epoch_1.pth")
+    ckpt = torch.load(work / "epoch_1.pth", weights_only=False)      # written by this run
+    assert ckpt["meta"]["iter"] == 2
+    assert all(bool(torch.isfinite(v).all()) for v in ckpt["state_dict"].values() if v.is_floating_point())

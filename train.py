@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Training CLI with the reference's flags (reference: train.py:36-124):
+"""Training entry point.  The command line is the reference's (reference: train.py:36-124), the
+launch model is this build's: one process per MI355X, started by torch.distributed.run.
 
   python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train.py \
-      --config config/cfg_kitti_tripleD.py --work_dir work/ [--resume_from ckpt] [--launcher pytorch]
+      --config config/cfg_kitti_tripleD.py --work_dir work/ [--resume_from ckpt]
 
-One process per GPU; gradients are averaged by the bucketed RCCL engine in mmcv.parallel."""
+  python train.py --launcher none ...        # one process, one GPU
+
+Gradients are exchanged by the flat parameter store / the bucketed RCCL engine (mmcv.parallel);
+precision, memory format and dispatch strictness come from the config (mono.apis.trainer.configure_execution)."""
 import argparse
 import os
 import sys
@@ -16,54 +20,69 @@ import tripled_amd  # noqa: F401,E402  (puts mono / mmcv on sys.path)
 
 import torch  # noqa: E402
 import mmcv  # noqa: E402
-from mmcv import Config  # noqa: E402
 from mmcv.runner import load_checkpoint  # noqa: E402
-from mono.apis import get_root_logger, init_dist, set_random_seed, train_mono  # noqa: E402
+from mono import apis  # noqa: E402
 from mono.datasets.get_dataset import get_dataset  # noqa: E402
 from mono.model.registry import MONO  # noqa: E402
 import mono.model  # noqa: F401,E402  (registers the model classes)
 
+FLAGS = (
+    # name(s), keyword arguments -- names and defaults as in the reference's CLI
+    (("--config",), dict(default=os.path.join(ROOT, "config", "cfg_kitti_tripleD.py"), help="config file")),
+    (("--work_dir",), dict(default=os.path.join(ROOT, "work_dirs", "tripled"), help="logs and checkpoints go here")),
+    (("--resume_from",), dict(default=None, help="checkpoint to resume (weights, optimiser state, epoch/iter)")),
+    (("--gpus",), dict(default="0", help="comma-separated device ids of a --launcher none run")),
+    (("--seed",), dict(type=int, default=1024)),
+    (("--launcher",), dict(choices=("none", "pytorch"), default="pytorch",
+                           help="pytorch: ranks started by torch.distributed.run; none: a single process")),
+    (("--local_rank", "--local-rank"), dict(type=int, default=0, help="accepted for old launchers; LOCAL_RANK is what is read")),
+)
 
-def parse_args():
-    p = argparse.ArgumentParser(description="Train a self-supervised depth model")
-    p.add_argument("--config", default=os.path.join(ROOT, "config", "cfg_kitti_tripleD.py"), help="train config file path")
-    p.add_argument("--work_dir", default=os.path.join(ROOT, "work_dirs", "tripled"), help="the dir to save logs and models")
-    p.add_argument("--resume_from", help="the checkpoint file to resume from")
-    p.add_argument("--gpus", default="0", type=str, help="gpu ids (only applicable to non-distributed training)")
-    p.add_argument("--seed", type=int, default=1024, help="random seed")
-    p.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="pytorch", help="job launcher")
-    p.add_argument("--local_rank", "--local-rank", type=int, default=0)
-    return p.parse_args()
 
-
-def main():
-    args = parse_args()
-    cfg = Config.fromfile(args.config)
+def read_job(argv=None):
+    """Command line + config file -> the cfg object train_mono() consumes."""
+    parser = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for names, kw in FLAGS:
+        parser.add_argument(*names, **kw)
+    args = parser.parse_args(argv)
+    cfg = mmcv.Config.fromfile(args.config)
     cfg.work_dir = args.work_dir
-    if cfg.get("cudnn_benchmark", False):
-        torch.backends.cudnn.benchmark = True     # MIOpen find-mode on ROCm
-    if args.resume_from is not None:
+    cfg.gpus = [int(tok) for tok in args.gpus.split(",") if tok != ""]
+    if args.resume_from:
         cfg.resume_from = args.resume_from
-    cfg.gpus = [int(g) for g in args.gpus.split(",")]
-    distributed = args.launcher != "none"
-    if distributed:
-        init_dist(args.launcher, **cfg.dist_params)
-    logger = get_root_logger(cfg.log_level)
-    logger.info("Distributed training: {}".format(distributed))
-    if args.seed is not None:
-        logger.info("Set random seed to {}".format(args.seed))
-        set_random_seed(args.seed)
-    model = MONO.module_dict[cfg.model["name"]](cfg.model)
+    return args, cfg
+
+
+def initial_weights(model, cfg):
+    """resume_from wins over finetune; both are read without executing anything from the file."""
     if cfg.resume_from is not None:
         load_checkpoint(model, cfg.resume_from, map_location="cpu")
-    elif cfg.finetune is not None:
-        ckpt = torch.load(cfg.finetune, map_location="cpu", weights_only=False)
-        model.load_state_dict(ckpt["state_dict"], strict=False)
-    train_dataset = get_dataset(cfg.data, training=True)
-    val_dataset = get_dataset(cfg.data, training=False) if cfg.validate else None
-    mmcv.mkdir_or_exist(os.path.abspath(cfg.work_dir))
-    cfg.dump(os.path.join(cfg.work_dir, os.path.basename(args.config)))
-    train_mono(model, train_dataset, val_dataset, cfg, distributed=distributed, validate=cfg.validate)
+        return
+    if cfg.get("finetune") is not None:
+        blob = torch.load(cfg.finetune, map_location="cpu", weights_only=True)
+        model.load_state_dict(blob.get("state_dict", blob), strict=False)
+
+
+def main(argv=None):
+    args, cfg = read_job(argv)
+    torch.backends.cudnn.benchmark = bool(cfg.get("cudnn_benchmark", False))     # = MIOpen find mode on ROCm
+    multi_rank = args.launcher != "none"
+    if multi_rank:
+        apis.init_dist(args.launcher, **cfg.dist_params)
+    log = apis.get_root_logger(cfg.log_level)
+    log.info("launcher=%s  seed=%s  config=%s", args.launcher, args.seed, args.config)
+    if args.seed is not None:
+        apis.set_random_seed(args.seed)
+
+    model = MONO.module_dict[cfg.model["name"]](cfg.model)
+    initial_weights(model, cfg)
+    splits = {"train": get_dataset(cfg.data, training=True),
+              "val": get_dataset(cfg.data, training=False) if cfg.validate else None}
+
+    out_dir = os.path.abspath(cfg.work_dir)
+    mmcv.mkdir_or_exist(out_dir)
+    cfg.dump(os.path.join(out_dir, os.path.basename(args.config)))      # the run keeps a copy of its config
+    apis.train_mono(model, splits["train"], splits["val"], cfg, distributed=multi_rank, validate=cfg.validate)
 
 
 if __name__ == "__main__":
