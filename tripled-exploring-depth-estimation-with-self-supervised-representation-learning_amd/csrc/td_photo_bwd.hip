@@ -41,7 +41,8 @@ struct PhotoBwdArgs {
 };
 
 template <int NS>
-__global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
+// second bound: two waves per SIMD (<= 256 registers); without it the two-row body is scheduled into 278
+__global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int bid = (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3);
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
       const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
       const UpIdx uy = up_index(qc, ratio_y, a.hs);
       const unsigned o0 = (unsigned)(uy.i0 * a.ws), o1 = (unsigned)(uy.i1 * a.ws);
-      d4[0] = dispb[o0 + (unsigned)ux.i0]; d4[1] = dispb[o0 + (unsigned)ux.i1];
-      d4[2] = dispb[o1 + (unsigned)ux.i0]; d4[3] = dispb[o1 + (unsigned)ux.i1];
+      d4[0] = ld_at(dispb, (o0 + (unsigned)ux.i0) * 4u); d4[1] = ld_at(dispb, (o0 + (unsigned)ux.i1) * 4u);
+      d4[2] = ld_at(dispb, (o1 + (unsigned)ux.i0) * 4u); d4[3] = ld_at(dispb, (o1 + (unsigned)ux.i1) * 4u);
       l0 = uy.l0; l1 = uy.l1;
     };
     auto issue_field = [&](int k, float* cf9, float* yq3, unsigned& am, unsigned& aq) {
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
       const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
       const unsigned offc = (unsigned)(rc * W + xc);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) cf9[i] = cfb[i * plane + offc];
+      for (int i = 0; i < 9; ++i) cf9[i] = ld_at(cfb + (size_t)i * plane, offc * 4u);
       am = amb[offc];
       const int q = r - 1;
       const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
       const unsigned offq = (unsigned)(qc * W + xc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) yq3[c] = tgtb[c * plane + offq];
+      for (int c = 0; c < 3; ++c) yq3[c] = ld_at(tgtb + (size_t)c * plane, offq * 4u);
       aq = amb[offq];
     };
     auto issue_warp = [&](int k, const float* d4, float l0, float l1) {
@@ -148,19 +149,26 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
     issue_field(1, cfB, yqB, amB, aqB);
     issue_warp(0, dv, ul0, ul1);
 
-#pragma unroll 1
-    for (int k = 0; k < NK; ++k) {
+    // One row of the march.  The pipelines are two-slot rings; instead of shifting them (cfA = cfB, p_hc[0] = p_hc[1],
+    // dv = dv_n: 100 of the 420 vector instructions of an iteration were register moves) the row is instantiated
+    // twice with the slot roles exchanged, so every load lands in the registers its consumer reads.
+    //   F0: field slot holding row k (consumed here, then refilled with row k + 2)   F1: row k + 1
+    //   D0: disparity slot of q(k) (dead: its warp was issued one row ago; refilled with q(k + 2))   D1: q(k + 1)
+    //   pOld / pNew: horizontal coefficient sums of rows k - 2 / k - 1 (pOld receives row k)
+    auto row = [&](const int k, float (&cf0)[9], float (&yq0)[3], unsigned& am0, unsigned& aq0,
+                   float (&d0)[4], float& d0l0, float& d0l1, const float (&d1)[4], const float d1l0, const float d1l1,
+                   float (&pOld)[9], const float (&pNew)[9]) __attribute__((always_inline)) {
       // ---- consume: coefficient row r, warp of row q = r-1 ----
       const int r_k = y0 - 1 + k;
       const bool inside = r_k >= 0 && r_k < H && col_in;
-      const float m_k = (inside && (int)amA == sel) ? g_ssim : 0.f;
+      const float m_k = (inside && (int)am0 == sel) ? g_ssim : 0.f;
       const int q_k = r_k - 1;
-      const float ml1 = (q_k >= 0 && q_k < H && (int)aqA == sel) ? g_l1 : 0.f;
+      const float ml1 = (q_k >= 0 && q_k < H && (int)aq0 == sel) ? g_l1 : 0.f;
       float cf[9], xq[3], yv[3], dxi[3], dyi[3];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) cf[i] = cfA[i] * m_k;
+      for (int i = 0; i < 9; ++i) cf[i] = cf0[i] * m_k;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { xq[c] = 0.f; yv[c] = yqA[c]; dxi[c] = 0.f; dyi[c] = 0.f; }
+      for (int c = 0; c < 3; ++c) { xq[c] = 0.f; yv[c] = yq0[c]; dxi[c] = 0.f; dyi[c] = 0.f; }
       if (k >= 2) {                                   // rows above the chunk have no warp (see issue_warp)
         const float ex = (float)tap.x0 + 1.f - tap.ix, wx = tap.ix - (float)tap.x0;
         const float ey = (float)tap.y0 + 1.f - tap.iy, wy = tap.iy - (float)tap.y0;
@@ -177,18 +185,10 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
         }
       }
       const float dq = depth_q;
-      // ---- advance the pipelines (rows beyond the chunk are clamped duplicates, never consumed) ----
-#pragma unroll
-      for (int i = 0; i < 9; ++i) cfA[i] = cfB[i];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) yqA[c] = yqB[c];
-      amA = amB; aqA = aqB;
-      issue_field(k + 2, cfB, yqB, amB, aqB);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dv[i] = dv_n[i];
-      ul0 = ul0_n; ul1 = ul1_n;
-      issue_disp(y0 + k, dv_n, ul0_n, ul1_n);        // q of k + 2
-      issue_warp(k + 1, dv, ul0, ul1);
+      // ---- refill the slots just consumed (rows beyond the chunk are clamped duplicates, never consumed) ----
+      issue_field(k + 2, cf0, yq0, am0, aq0);
+      issue_disp(y0 + k, d0, d0l0, d0l1);            // q of k + 2
+      issue_warp(k + 1, d1, d1l0, d1l1);
 
       // ---- box filter of the coefficient field -> gradient w.r.t. the warped pixel of row q ----
       const int q = y0 - 2 + k;
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const float hc = (wl * lane_left(cf[i]) + cf[i]) + wr * lane_right(cf[i]);
-        const float G = wy0 * p_hc[0][i] + p_hc[1][i] + wy2 * hc;
+        const float G = wy0 * pOld[i] + pNew[i] + wy2 * hc;
         const int c = i / 3, t = i % 3;
         gw[c] += (t == 0) ? G : (t == 1 ? G * xq[c] : G * yv[c]);
-        p_hc[0][i] = p_hc[1][i]; p_hc[1][i] = hc;
+        pOld[i] = hc;
       }
       if (k >= 2 && q < H && col_out) {
         float du = 0.f, dvv = 0.f;
@@ -230,7 +230,14 @@ __global__ __launch_bounds__(BS_WAVES * 64) void photo_bwd_kernel(const PhotoBwd
         float* dst = dupb + (unsigned)(q * W + x);
         if (f == 0) *dst = contrib; else *dst += contrib;
       }
+    };
+    int k = 0;
+#pragma unroll 1
+    for (; k + 1 < NK; k += 2) {
+      row(k, cfA, yqA, amA, aqA, dv, ul0, ul1, dv_n, ul0_n, ul1_n, p_hc[0], p_hc[1]);
+      row(k + 1, cfB, yqB, amB, aqB, dv_n, ul0_n, ul1_n, dv, ul0, ul1, p_hc[1], p_hc[0]);
     }
+    if (k < NK) row(k, cfA, yqA, amA, aqA, dv, ul0, ul1, dv_n, ul0_n, ul1_n, p_hc[0], p_hc[1]);
 #pragma unroll
     for (int e = 0; e < 12; ++e) {
       const float tot = wave_sum(dP[e]);
