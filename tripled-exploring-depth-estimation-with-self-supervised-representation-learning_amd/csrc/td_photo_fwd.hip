@@ -9,6 +9,8 @@
 // taps of row r+2 are in flight, so a wave keeps ~30 loads outstanding without relying on
 // occupancy.  Blocks are remapped so that consecutive tasks (neighbouring strips / row chunks
 // that share halo lines) land on the same XCD and hit its L2.
+#include <type_traits>
+
 #include "td_common.h"
 
 namespace td {
@@ -113,19 +115,19 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
     const int qy = reflect1(y0 - 1 + k, H);
     const UpIdx uy = up_index(qy, ratio_y, a.hs);
     d.ur.o0 = uy.i0 * a.ws; d.ur.o1 = uy.i1 * a.ws; d.ur.l0 = uy.l0; d.ur.l1 = uy.l1;
-    d.v[0] = dispb[(unsigned)(d.ur.o0 + ux.i0)]; d.v[1] = dispb[(unsigned)(d.ur.o0 + ux.i1)];
-    d.v[2] = dispb[(unsigned)(d.ur.o1 + ux.i0)]; d.v[3] = dispb[(unsigned)(d.ur.o1 + ux.i1)];
+    d.v[0] = ld_at(dispb, (unsigned)(d.ur.o0 + ux.i0) * 4u); d.v[1] = ld_at(dispb, (unsigned)(d.ur.o0 + ux.i1) * 4u);
+    d.v[2] = ld_at(dispb, (unsigned)(d.ur.o1 + ux.i0) * 4u); d.v[3] = ld_at(dispb, (unsigned)(d.ur.o1 + ux.i1) * 4u);
   };
   auto stage_b = [&](int k, const DispTaps& d, RowLoads<NS>& L) {   // taps + gathers of pipeline row k
     const int qy = reflect1(y0 - 1 + k, H);
     const unsigned off = (unsigned)(qy * W + qx);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) L.yv[c] = tgtb[c * plane + off];
+    for (int c = 0; c < 3; ++c) L.yv[c] = ld_at(tgtb + (size_t)c * plane, off * 4u);
     if (IDENT) {
 #pragma unroll
       for (int f = 0; f < NS; ++f)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) L.xv[f][c] = srcb[f][c * plane + off];
+        for (int c = 0; c < 3; ++c) L.xv[f][c] = ld_at(srcb[f] + (size_t)c * plane, off * 4u);
     } else {
       const float dd = d.ur.l0 * (ux.l0 * d.v[0] + ux.l1 * d.v[1]) + d.ur.l1 * (ux.l0 * d.v[2] + ux.l1 * d.v[3]);
       const float depth = fast_rcp(a.min_disp + a.disp_range * dd);
@@ -147,10 +149,10 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
         orow = orow < 0 ? 0 : (orow > H - 1 ? H - 1 : orow);
         const unsigned pix = (unsigned)(orow * W + xo);
 #pragma unroll
-        for (int f = 0; f < NS; ++f) L.idv[f] = a.idloss[(size_t)(b * NS + f) * plane + pix];
+        for (int f = 0; f < NS; ++f) L.idv[f] = ld_at(a.idloss + (size_t)(b * NS + f) * plane, pix * 4u);
         if (MODE >= 3) {
 #pragma unroll
-          for (int f = 0; f < NS; ++f) L.nz[f] = a.noise[(size_t)(f * a.B + b) * plane + pix];
+          for (int f = 0; f < NS; ++f) L.nz[f] = ld_at(a.noise + (size_t)(f * a.B + b) * plane, pix * 4u);
         }
       }
     }
@@ -168,8 +170,12 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   }
   float acc = 0.f;
 
-  // consume pipeline row k from `cur`; EMIT: a full 3-row window is available
-  auto consume = [&](int k, const RowLoads<NS>& cur, bool emit_allowed) {
+  // consume pipeline row k from `cur`; emit_allowed: a full 3-row window is available.  The two-row rings are not
+  // shifted: ring slot RO = k & 1 holds the older row and receives this row's sums (the loop is unrolled by two, so
+  // RO is a compile-time constant).  In the backward this form removed 40 register moves per row; here the
+  // compiler had already coalesced the shifts of the unrolled loop (same instruction count either way)
+  auto consume = [&](auto ro_tag, int k, const RowLoads<NS>& cur, bool emit_allowed) {
+    constexpr int RO = decltype(ro_tag)::value, RN = 1 - RO;
     float y[3], xw[NS][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) y[c] = cur.yv[c];
@@ -200,13 +206,13 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
         hxy[f] = hsum3(xw[f][c] * y[c]);
       }
       if (emit_allowed) {
-        const float sy = p_hy[0][c] + p_hy[1][c] + hy;
-        const float syy = p_hyy[0][c] + p_hyy[1][c] + hyy;
+        const float sy = p_hy[RO][c] + p_hy[RN][c] + hy;
+        const float syy = p_hyy[RO][c] + p_hyy[RN][c] + hyy;
 #pragma unroll
         for (int f = 0; f < NS; ++f) {
-          const float sx = p_hx[0][f][c] + p_hx[1][f][c] + hx[f];
-          const float sxx = p_hxx[0][f][c] + p_hxx[1][f][c] + hxx[f];
-          const float sxy = p_hxy[0][f][c] + p_hxy[1][f][c] + hxy[f];
+          const float sx = p_hx[RO][f][c] + p_hx[RN][f][c] + hx[f];
+          const float sxx = p_hxx[RO][f][c] + p_hxx[RN][f][c] + hxx[f];
+          const float sxy = p_hxy[RO][f][c] + p_hxy[RN][f][c] + hxy[f];
           if (COEF) {
             float al, be, ga;
             ss[f] += ssim_with_adjoint(sx, sy, sxx, syy, sxy, al, be, ga);
@@ -218,14 +224,14 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
           l1[f] += fast_sqrt(df * df + TD_L1_EPS2);
         }
       }
-      p_hy[0][c] = p_hy[1][c]; p_hy[1][c] = hy;
-      p_hyy[0][c] = p_hyy[1][c]; p_hyy[1][c] = hyy;
+      p_hy[RO][c] = hy;
+      p_hyy[RO][c] = hyy;
       c_y[c] = y[c];
 #pragma unroll
       for (int f = 0; f < NS; ++f) {
-        p_hx[0][f][c] = p_hx[1][f][c]; p_hx[1][f][c] = hx[f];
-        p_hxx[0][f][c] = p_hxx[1][f][c]; p_hxx[1][f][c] = hxx[f];
-        p_hxy[0][f][c] = p_hxy[1][f][c]; p_hxy[1][f][c] = hxy[f];
+        p_hx[RO][f][c] = hx[f];
+        p_hxx[RO][f][c] = hxx[f];
+        p_hxy[RO][f][c] = hxy[f];
         c_x[f][c] = xw[f][c];
       }
     }
@@ -281,22 +287,24 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   // prologue: rows 0 and 1 only fill the window
   if (!IDENT) stage_a(2, DA);
   stage_b(1, DB, LB);
-  consume(0, LA, false);
+  constexpr std::integral_constant<int, 0> even{};
+  constexpr std::integral_constant<int, 1> odd{};
+  consume(even, 0, LA, false);
   if (!IDENT) stage_a(3, DB);
   stage_b(2, DA, LA);
-  consume(1, LB, false);
+  consume(odd, 1, LB, false);
 #pragma unroll 1
   for (int k = 2; k < NK - 2; k += 2) {
     if (!IDENT) stage_a(k + 2, DA);
     stage_b(k + 1, DB, LB);
-    consume(k, LA, true);
+    consume(even, k, LA, true);
     if (!IDENT) stage_a(k + 3, DB);      // rows >= NK are clamped duplicates, never consumed
     stage_b(k + 2, DA, LA);
-    consume(k + 1, LB, true);
+    consume(odd, k + 1, LB, true);
   }
   stage_b(NK - 1, DB, LB);
-  consume(NK - 2, LA, true);
-  consume(NK - 1, LB, true);
+  consume(even, NK - 2, LA, true);
+  consume(odd, NK - 1, LB, true);
 
   if (!IDENT) {
     const float tot = wave_sum(acc);
