@@ -41,7 +41,7 @@ struct PhotoBwdArgs {
 };
 
 template <int NS>
-// second bound: two waves per SIMD (<= 256 registers); without it the two-row body is scheduled into 278
+// second bound: two waves per SIMD (<= 256 registers, no spills); without it the two-row body is scheduled into 278
 __global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -175,7 +175,13 @@ __global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const Photo
         const float mx = tap.gmx * sx_scale, my = tap.gmy * sy_scale;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          xq[c] = blend_taps(tv[c], tap);
+          // weights re-formed here instead of carried across the row (4 registers); (float)x0 == floor(ix) after the
+          // clamp, so these are the forward's ex * ey, ... bit for bit, summed in ATen's order nw, ne, sw, se
+          float o = tv[c].nw * (ex * ey);
+          o += tv[c].ne * (wx * ey);
+          o += tv[c].sw * (ex * wy);
+          o += tv[c].se * (wx * wy);
+          xq[c] = o;
           const float vnw = tv[c].nw;
           const float vne = tap.in_e ? tv[c].ne : 0.f;
           const float vsw = tap.in_s ? tv[c].sw : 0.f;
