@@ -50,7 +50,7 @@ def main():
         cfg.data["gt_depth_path"] = args.gt_depths
     cfg.model["imgs_per_gpu"] = 1
     model = MONO.module_dict[cfg.model["name"]](cfg.model)
-    ckpt = torch.load(args.checkpoint, map_location="cpu", weights_only=False)
+    ckpt = torch.load(args.checkpoint, map_location="cpu", weights_only=True)      # executes nothing from the file
     model.load_state_dict(ckpt["state_dict"], strict=True)
     mean, ratios = evaluate(model, get_dataset(cfg.data, training=False), bool(cfg.data["stereo_scale"]), args.device)
     med = np.median(ratios)

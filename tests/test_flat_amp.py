@@ -1,6 +1,7 @@
 """FlatMixedPrecision == autocast + clip_grad_norm_ + Adam on the same model (CPU, bf16 autocast)."""
 import copy
 
+import pytest
 import torch
 import torch.nn as nn
 
@@ -116,3 +117,48 @@ def test_full_precision_context_swaps_weights():
         y = net(torch.randn(1, 3, 8, 8))          # plain fp32 forward, no autocast needed
         assert y.dtype == torch.float32
     assert net[0].weight.dtype == torch.bfloat16
+
+
+def test_plain_checkpoint_resumes_into_the_flat_store():
+    """A checkpoint written by the per-parameter path (torch.optim.Adam with its own execution flags in the param
+    group) resumes into the flat store: hyper-parameters are taken, execution flags are not, `step` lives where the
+    running optimiser needs it."""
+    x = torch.randn(4, 3, 12, 16)
+    ref = _net()
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref(x).float().square().mean().backward()
+        opt.step()
+    osd = copy.deepcopy(opt.state_dict())
+    osd["param_groups"][0].update(capturable=True, fused=True, foreach=False)      # flags of some other process
+    net = _net()
+    flat = FlatMixedPrecision(net, lr=1e-2)
+    before = {k: flat.optimizer.param_groups[0].get(k) for k in ("capturable", "fused", "foreach", "differentiable")}
+    flat.load_module_state_dict(net, ref.state_dict(), strict=True)
+    flat.load_optimizer_state_dict(net, osd)
+    group = flat.optimizer.param_groups[0]
+    assert group["lr"] == 5e-3
+    assert {k: group.get(k) for k in before} == before
+    st = flat.optimizer.state[flat.master]
+    assert float(st["step"]) == 2.0 and st["step"].device == flat.flat_w.device
+    _flat_step(flat, net, x)
+    assert float(st["step"]) == 3.0 and bool(torch.isfinite(flat.flat_w).all())
+    # and the file the store writes carries no execution flags either
+    written = flat.optimizer_state_dict(net)["param_groups"][0]
+    assert not {"capturable", "fused", "foreach", "differentiable"} & set(written)
+
+
+def test_shape_mismatch_is_reported_not_broadcast():
+    net = _net()
+    flat = FlatMixedPrecision(net, lr=1e-2)
+    sd = flat.module_state_dict(net)
+    bad = dict(sd)
+    bad["0.weight"] = torch.zeros(1, 1, 1, 1)            # broadcastable onto [8,3,3,3]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        flat.load_module_state_dict(net, bad)
+    bad = dict(sd)
+    bad["1.running_mean"] = torch.zeros(1)               # a buffer
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        flat.load_module_state_dict(net, bad)

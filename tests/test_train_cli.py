@@ -90,6 +90,37 @@ def test_finetune_weights_are_loaded_safely(tmp_path):
         train.initial_weights(net, Config(dict(resume_from=None, finetune=str(tmp_path / "bad.pth"))))
 
 
+def test_resume_refuses_a_code_carrying_pickle(tmp_path):
+    """--resume_from goes through mmcv.runner.load_checkpoint / Runner.resume: weights_only, read once."""
+    import logging
+    import tripled_amd  # noqa: F401
+    from mmcv.runner import Runner, load_checkpoint
+    net = torch.nn.Sequential(torch.nn.Linear(3, 2))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    net(torch.randn(4, 3)).sum().backward()
+    opt.step()
+    good = {"meta": {"epoch": 2, "iter": 7, "mmcv_version": "0.4.4", "time": "now"},
+            "state_dict": {k: v + 1 for k, v in net.state_dict().items()}, "optimizer": opt.state_dict()}
+    torch.save(good, tmp_path / "ok.pth")
+    runner = Runner(net, lambda *a, **k: {}, opt, str(tmp_path), logging.WARNING)
+    runner.resume(str(tmp_path / "ok.pth"), map_location="cpu")
+    assert (runner.epoch, runner.iter) == (2, 7)
+    assert all(torch.equal(v, good["state_dict"][k]) for k, v in net.state_dict().items())
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save(dict(good, meta=dict(good["meta"], payload=Evil())), tmp_path / "bad.pth")
+    with pytest.raises(Exception, match="(?i)weights_only|unsupported|unpickl"):
+        load_checkpoint(net, str(tmp_path / "bad.pth"), map_location="cpu")
+    with pytest.raises(Exception):
+        runner.resume(str(tmp_path / "bad.pth"), map_location="cpu")
+    # train.py leaves the resume file to the runner (it is not read twice)
+    train = _train_module()
+    from mmcv import Config
+    train.initial_weights(net, Config(dict(resume_from=str(tmp_path / "bad.pth"), finetune=None)))
+
+
 @pytest.mark.gpu
 def test_train_main_single_process(tmp_path):
     """`python train.py --launcher none` end to end: config file -> model -> two iterations -> checkpoint + config copy."""

@@ -20,7 +20,6 @@ import tripled_amd  # noqa: F401,E402  (puts mono / mmcv on sys.path)
 
 import torch  # noqa: E402
 import mmcv  # noqa: E402
-from mmcv.runner import load_checkpoint  # noqa: E402
 from mono import apis  # noqa: E402
 from mono.datasets.get_dataset import get_dataset  # noqa: E402
 from mono.model.registry import MONO  # noqa: E402
@@ -54,9 +53,10 @@ def read_job(argv=None):
 
 
 def initial_weights(model, cfg):
-    """resume_from wins over finetune; both are read without executing anything from the file."""
+    """resume_from wins over finetune: the runner restores weights, optimiser state and epoch/iter from it
+    (Runner.resume -> mmcv.runner.load_checkpoint), once.  Both files are read with ``weights_only=True``:
+    nothing in them is executed."""
     if cfg.resume_from is not None:
-        load_checkpoint(model, cfg.resume_from, map_location="cpu")
         return
     if cfg.get("finetune") is not None:
         blob = torch.load(cfg.finetune, map_location="cpu", weights_only=True)

@@ -24,6 +24,8 @@ HOSTSIDE = os.path.join(PKG_DIR, "hostside")
 # section 6); the general replay path is correct.  The flag is read when the HIP runtime initialises, so it is
 # set on import of this package (before any HIP call); an explicit setting in the environment wins.
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# dmabuf IPC (what the host driver supports): RCCL's intra-node transport needs it before the first HIP call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def _activate():

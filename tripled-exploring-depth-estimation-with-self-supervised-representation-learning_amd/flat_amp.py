@@ -27,6 +27,9 @@ import torch.distributed as dist
 import torch.nn as nn
 
 ALIGN = 8      # elements: 16 B in bf16, 32 B in fp32
+# what a checkpoint's param_group carries across: the optimiser's hyper-parameters.  The execution flags (capturable,
+# fused, foreach, differentiable) belong to the process that runs the optimiser, not to the file.
+HYPER_KEYS = ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize", "initial_lr")
 
 
 class FlatMixedPrecision:
@@ -105,11 +108,14 @@ class FlatMixedPrecision:
     def load_module_state_dict(self, model, state_dict, strict=False):
         """Load fp32 weights into the master buffer (and refresh the bf16 working copy); buffers go through the module."""
         params = dict(model.named_parameters())
-        rest, missing = {}, []
+        rest, missing, mismatched = {}, [], []
         with torch.no_grad():
             for key, val in state_dict.items():
                 p = params.get(key)
                 if p is not None and id(p) in self._offset_of:
+                    if tuple(val.shape) != tuple(p.shape):      # as nn.Module.load_state_dict: report, never broadcast
+                        mismatched.append("%s: checkpoint %s vs model %s" % (key, tuple(val.shape), tuple(p.shape)))
+                        continue
                     self._master_view(p).copy_(val.to(self.flat_w.device, torch.float32))
                 else:
                     rest[key] = val
@@ -124,8 +130,13 @@ class FlatMixedPrecision:
         with torch.no_grad():
             for key, val in rest.items():
                 if key in own:
+                    if tuple(val.shape) != tuple(own[key].shape):
+                        mismatched.append("%s: checkpoint %s vs model %s" % (key, tuple(val.shape), tuple(own[key].shape)))
+                        continue
                     own[key].copy_(val)
         missing += [k for k in own if k not in state_dict]
+        if mismatched:
+            raise RuntimeError("size mismatch for " + "; ".join(mismatched))
         if strict and (missing or unexpected):
             raise RuntimeError("missing keys %s, unexpected keys %s" % (missing, unexpected))
         return missing, unexpected
@@ -142,7 +153,7 @@ class FlatMixedPrecision:
                 view = lambda buf: torch.as_strided(buf, p.size(), p.stride(), off).detach().clone()   # noqa: E731
                 state[i] = {"step": flat_state["step"].detach().clone(), "exp_avg": view(flat_state["exp_avg"]),
                             "exp_avg_sq": view(flat_state["exp_avg_sq"])}
-        pg = {k: v for k, v in group.items() if k != "params"}
+        pg = {k: group[k] for k in HYPER_KEYS if k in group}
         pg["params"] = list(range(len(order)))
         return {"state": state, "param_groups": [pg]}
 
@@ -151,15 +162,18 @@ class FlatMixedPrecision:
         order = [p for p in model.parameters() if p.requires_grad]
         if len(osd["param_groups"]) != 1 or len(osd["param_groups"][0]["params"]) != len(order):
             raise ValueError("optimizer state does not match the model: %d parameters expected" % len(order))
-        for k, v in osd["param_groups"][0].items():
-            if k != "params":
-                self.optimizer.param_groups[0][k] = v
+        own = self.optimizer.param_groups[0]
+        for k in HYPER_KEYS:
+            if k in osd["param_groups"][0]:
+                own[k] = osd["param_groups"][0][k]
         if not osd["state"]:
             return
         dev = self.flat_w.device
         st = self.optimizer.state[self.master]
         if not st:
-            st["step"] = torch.zeros((), dtype=torch.float32, device=dev if self.optimizer.param_groups[0].get("capturable") else "cpu")
+            # torch keeps `step` on the device whenever the optimiser is fused OR capturable
+            on_dev = bool(own.get("capturable") or own.get("fused"))
+            st["step"] = torch.zeros((), dtype=torch.float32, device=dev if on_dev else "cpu")
             st["exp_avg"] = torch.zeros_like(self.flat_w)
             st["exp_avg_sq"] = torch.zeros_like(self.flat_w)
         with torch.no_grad():

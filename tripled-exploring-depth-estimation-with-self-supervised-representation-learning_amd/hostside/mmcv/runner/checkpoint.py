@@ -40,7 +40,9 @@ def load_state_dict(module, state_dict, strict=False, logger=None):
 def load_checkpoint(model, filename, map_location=None, strict=False, logger=None):
     if not os.path.isfile(filename):
         raise IOError("{} is not a checkpoint file".format(filename))
-    checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
+    # weights_only: nothing in the file is executed.  A checkpoint in the mmcv 0.4.4 layout (meta of str/int, state_dict,
+    # optimizer.state_dict() of tensors and scalars) loads under it; a pickle that carries code is refused.
+    checkpoint = torch.load(filename, map_location=map_location, weights_only=True)
     if isinstance(checkpoint, OrderedDict):
         state_dict = checkpoint
     elif isinstance(checkpoint, dict) and "state_dict" in checkpoint:

@@ -46,10 +46,11 @@ def init_dist(launcher, backend="nccl", **kwargs):
                          "(launcher='pytorch')" % (launcher,))
     if dist.is_initialized():
         return
+    # the host driver only supports dmabuf IPC; RCCL's intra-node transport needs this before the first HIP call
+    # (tripled_amd/__init__ sets it on import as well; RankEnv.device() below may already initialise HIP)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env = RankEnv()
     dev = env.device()
-    # the host driver only supports dmabuf IPC; RCCL's intra-node transport needs this before the first HIP call
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if dev is None:
         dist.init_process_group("gloo" if backend == "nccl" else backend, **kwargs)
         return

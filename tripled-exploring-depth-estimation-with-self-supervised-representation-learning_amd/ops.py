@@ -781,9 +781,11 @@ class _PoseTransforms(torch.autograd.Function):
         n = len(ctx.invert)
         B = axisangle.shape[0] // n
         ga, gt = torch.empty_like(axisangle), torch.empty_like(translation)
+        gT_c = _f32c(gT) if gT is not None else None      # converted copies stay alive across the launch
+        gP_c = _f32c(gP) if gP is not None else None
         native.check(lib.td_pose_bwd(native.ptr(axisangle), native.ptr(translation), native.int_array(ctx.invert), native.ptr(K), n, B,
-                                     native.ptr(_f32c(gT)) if gT is not None else None,
-                                     native.ptr(_f32c(gP)) if gP is not None else None,
+                                     native.ptr(gT_c) if gT_c is not None else None,
+                                     native.ptr(gP_c) if gP_c is not None else None,
                                      native.ptr(ga), native.ptr(gt), native.stream()), "td_pose_bwd")
         return ga, gt, None, None
 
