@@ -80,9 +80,12 @@ def parse():
                    help="do not fail when a HIP-resident tensor takes an ATen composition instead of a hand-written kernel")
     p.add_argument("--cpu-batch", type=int, default=2)
     p.add_argument("--cpu-steps", type=int, default=3)
-    p.add_argument("--syncbn", default="off", choices=["on", "off"],
-                   help="N > 1: batch statistics over all ranks as in the config (syncbn=True; the hand-written BatchNorm passes "
-                        "with one small all-reduce per layer and direction) or local statistics (default, 12 images per GPU)")
+    p.add_argument("--syncbn", default="config", choices=["config", "on", "off"],
+                   help="N > 1: batch statistics over all ranks (the hand-written BatchNorm passes with one small all-reduce per "
+                        "layer and direction) or local statistics; default: what the config says (cfg_kitti_tripleD: syncbn=True)")
+    p.add_argument("--entry", default="both", choices=["step", "runner", "both"],
+                   help="step: tripled_amd.step.TrainStep replayed by this script (`value`); runner: the same iteration through "
+                        "train_mono / the mmcv Runner, i.e. what train.py executes (`runner_entry`); both (default)")
     p.add_argument("--grad-sync", default="auto", choices=["auto", "overlap-graph", "two-graph", "eager"],
                    help="N > 1 gradient exchange (auto: overlap-graph, falling back to two-graph, then eager)")
     p.add_argument("--miopen-find", default="config", choices=["config", "on", "off"],
@@ -227,6 +230,47 @@ CONV_GFLOP_PER_IMG = {(192, 640): 377.2, (320, 1024): 911.9}
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
+def runner_entry(args, batch, world, dev):
+    """The same workload through the reference's entry path: mono.apis.train_mono -> mmcv Runner.run -> hooks ->
+    tripled_amd.step.RunnerIteration (what ``train.py`` executes per batch; reference: train.py:70-124,
+    mono/apis/trainer.py:147-189), on the same HBM-resident batch.  Returns ms per iteration over ``args.steps`` iterations
+    after the eager + capture + health-check iterations."""
+    import shutil
+    import tempfile
+    from mono.apis import train_mono
+    from mono.datasets import ResidentBatches
+    cfg = Config.fromfile(args.config)
+    warm = max(args.warmup, int(cfg.get("graph_warmup_iters", 3)) + 4)
+    work = tempfile.mkdtemp(prefix="td_bench_runner_")
+    cfg.work_dir, cfg.gpus, cfg.total_epochs, cfg.validate = work, [0], 1, False
+    cfg.checkpoint_config = dict(interval=-1)             # no 1.3 GB file at the end of the epoch
+    cfg.log_config = dict(interval=10 ** 9, hooks=[dict(type="TextLoggerHook")])
+    cfg.log_level = "WARNING"
+    cfg.strict_dispatch = not args.allow_fallbacks
+    if args.dtype == "fp32":
+        cfg.amp = "fp32"
+    if args.no_graph:
+        cfg.hip_graph = False
+    if world > 1:
+        cfg.syncbn = bool(cfg.get("syncbn", False)) if args.syncbn == "config" else args.syncbn == "on"
+    torch.manual_seed(1024)
+    model = MONO.module_dict[cfg.model["name"]](cfg.model)
+    data = ResidentBatches(batch, warm + args.steps, timed_from=warm)
+    try:
+        train_mono(model, data, None, cfg, distributed=world > 1, validate=False)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    elapsed = data.elapsed
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final = float(torch.stack([p.detach().float().abs().max() for p in model.parameters()]).max())
+    if final != final or final == float("inf"):
+        raise NonFiniteLossError("runner entry: a parameter is not finite after %d iterations" % (warm + args.steps))
+    return elapsed / data.timed_iters * 1e3
+
+
 def cpu_baseline(cfg_path, batch_size, steps):
     """The same training step on the host: fp32 networks + the CPU oracle loss path (a port of
     the reference's unfused PyTorch ops, pinned against the reference in tests/)."""
@@ -286,7 +330,7 @@ def main():
     from mono.model.networks import set_fp8_conv1x1
     set_fp8_conv1x1(args.fp8)
     model = build_model(cfg, dev, channels_last=True)
-    use_syncbn = args.syncbn == "on"
+    use_syncbn = bool(cfg.get("syncbn", False)) if args.syncbn == "config" else args.syncbn == "on"
     dtype = torch.bfloat16 if args.dtype == "bf16" else None
     dp = world > 1 or os.environ.get("TD_FORCE_DP") == "1"      # TD_FORCE_DP: rehearse the N > 1 code path in a one-rank group
     if dp and not dist.is_initialized():
@@ -483,6 +527,17 @@ def main():
             dist.destroy_process_group()
         raise SystemExit(3)
 
+    # the same workload through train.py's path (train_mono -> Runner -> RunnerIteration).  N > 1: only on request -- a
+    # failure there would involve collectives, and the headline line must not depend on it
+    runner_ms, runner_err = None, None
+    if args.entry == "runner" or (args.entry == "both" and world == 1):
+        try:
+            runner_ms = runner_entry(args, batch, world, dev)
+        except NonFiniteLossError:
+            raise
+        except Exception as e:      # noqa: BLE001 -- reported in the line, never loses it
+            runner_err = "%s: %s" % (type(e).__name__, str(e)[:300])
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
@@ -496,6 +551,8 @@ def main():
             "config": {"workload": "%s %dx%d bs=%d/GPU (%s), fwd+bwd+clip+Adam" % (
                 m["name"], H, W, B, os.path.basename(args.config)), "global_batch": world * B,
                 "parallelism": "dp%d" % world, "hip_graph": graphed,
+                "entry": "tripled_amd.step.TrainStep replayed by bench.py (`value`); `runner_entry` = the same iteration "
+                         "through mono.apis.train_mono / Runner.run, i.e. train.py's path",
                 "syncbn": bool(use_syncbn and dp),
                 "param_store": ("flat fp32 master + bf16 working copy" if step.flat is not None and lowp_store and used_mode != "overlap-graph"
                                 else ("flat fp32" if step.flat is not None else "per-parameter")),
@@ -510,6 +567,13 @@ def main():
                 "fallbacks": sum(dispatch.fallbacks.values()), "td_abi_calls_per_step": td_calls_per_step,
                 "loss_after_warmup": round(loss_after_warmup, 6), "final_loss": round(final_loss, 6), "valid": True},
         }
+        if runner_ms is not None:
+            line["runner_entry"] = {"ms_per_step": round(runner_ms, 3), "value": round(world * B / (runner_ms * 1e-3), 3),
+                                    "unit": "imgs/s", "vs_step_entry": round(ms / runner_ms, 4),
+                                    "what": "train_mono -> Runner.run -> hooks -> RunnerIteration (HIP-graph replay), same batch "
+                                            "resident in HBM, %d timed iterations" % args.steps}
+        elif runner_err is not None:
+            line["runner_entry"] = {"error": runner_err}
         if not args.no_roofline:
             kern = roofline_of_hot_kernels(cfg, batch)
             dom = max(kern, key=lambda k: kern[k]["seconds"])

@@ -23,7 +23,18 @@ HOSTSIDE = os.path.join(PKG_DIR, "hostside")
 # step wrongly (garbage loss terms / NaN gradients from the second replay on, tools/diag_capture.py, DESIGN.md
 # section 6); the general replay path is correct.  The flag is read when the HIP runtime initialises, so it is
 # set on import of this package (before any HIP call); an explicit setting in the environment wins.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+def _packet_capture_off_at_hip_init():
+    preset = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+    if preset is not None:
+        return preset == "0"
+    torch_mod = sys.modules.get("torch")
+    hip_up = bool(torch_mod is not None and torch_mod.cuda.is_initialized())
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    return not hip_up       # set now; it only takes effect if the runtime has not started yet
+
+
+# step.capture_step refuses a single-stream capture when this is False
+PACKET_CAPTURE_OFF_AT_HIP_INIT = _packet_capture_off_at_hip_init()
 # dmabuf IPC (what the host driver supports): RCCL's intra-node transport needs it before the first HIP call
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 

@@ -153,7 +153,12 @@ class FlatMixedPrecision:
                 view = lambda buf: torch.as_strided(buf, p.size(), p.stride(), off).detach().clone()   # noqa: E731
                 state[i] = {"step": flat_state["step"].detach().clone(), "exp_avg": view(flat_state["exp_avg"]),
                             "exp_avg_sq": view(flat_state["exp_avg_sq"])}
-        pg = {k: group[k] for k in HYPER_KEYS if k in group}
+        def plain(v):      # a device-side lr tensor goes to the file as the number the host wrote into it
+            if not torch.is_tensor(v):
+                return v
+            host = getattr(v, "_host_value", None)
+            return host if host is not None else float(v)
+        pg = {k: plain(group[k]) for k in HYPER_KEYS if k in group}
         pg["params"] = list(range(len(order)))
         return {"state": state, "param_groups": [pg]}
 
@@ -165,7 +170,11 @@ class FlatMixedPrecision:
         own = self.optimizer.param_groups[0]
         for k in HYPER_KEYS:
             if k in osd["param_groups"][0]:
-                own[k] = osd["param_groups"][0][k]
+                if torch.is_tensor(own.get(k)):      # a device-side lr (read by a captured step): keep the tensor
+                    own[k].fill_(float(osd["param_groups"][0][k]))
+                    own[k]._host_value = float(osd["param_groups"][0][k])
+                else:
+                    own[k] = osd["param_groups"][0][k]
         if not osd["state"]:
             return
         dev = self.flat_w.device

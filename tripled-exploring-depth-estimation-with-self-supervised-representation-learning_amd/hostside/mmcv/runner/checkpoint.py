@@ -62,6 +62,14 @@ def weights_to_cpu(state_dict):
     return out
 
 
+def _plain_numbers(osd):
+    """optimizer.state_dict() with 0-d tensor hyper-parameters (the device-side lr of a graph-replayed run) as floats:
+    the file keeps the reference's layout whatever the execution mode of the run that wrote it."""
+    from .hooks import lr_value
+    groups = [{k: (lr_value(v) if torch.is_tensor(v) and v.dim() == 0 else v) for k, v in g.items()} for g in osd["param_groups"]]
+    return {"state": osd["state"], "param_groups": groups}
+
+
 def save_checkpoint(model, filename, optimizer=None, meta=None):
     meta = {} if meta is None else dict(meta)
     from .. import __version__
@@ -72,5 +80,5 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
     checkpoint = {"meta": meta, "state_dict": weights_to_cpu(weights)}
     if optimizer is not None:
         # with the flat store the optimiser runs on ONE flat parameter; the file keeps the per-parameter layout
-        checkpoint["optimizer"] = flat.optimizer_state_dict(module) if flat is not None else optimizer.state_dict()
+        checkpoint["optimizer"] = flat.optimizer_state_dict(module) if flat is not None else _plain_numbers(optimizer.state_dict())
     torch.save(checkpoint, filename)

@@ -21,6 +21,13 @@ def get_priority(priority):
     raise TypeError("priority must be an integer or a priority name")
 
 
+def lr_value(lr):
+    """A learning rate as a plain number.  A device-side lr tensor (graph replay reads it) carries the exact value the host
+    wrote last in ``_host_value``: no device sync, and no fp32 rounding of the schedule's base value."""
+    host = getattr(lr, "_host_value", None)
+    return host if host is not None else float(lr)
+
+
 class Hook:
     def before_run(self, runner): pass
     def after_run(self, runner): pass
@@ -77,7 +84,15 @@ class LrUpdaterHook(Hook):
 
     def _set_lr(self, runner, lr_groups):
         for group, lr in zip(runner.optimizer.param_groups, lr_groups):
-            group["lr"] = lr
+            cur = group["lr"]
+            if torch.is_tensor(cur):
+                # a device-side learning rate (the iteration is replayed from a HIP graph that reads this tensor):
+                # written in place, and only when the schedule moves it; the host keeps the value it wrote last
+                if getattr(cur, "_host_value", None) != lr:
+                    cur.fill_(lr)
+                    cur._host_value = lr
+            else:
+                group["lr"] = lr
 
     def get_lr(self, runner, base_lr):
         raise NotImplementedError
@@ -96,7 +111,8 @@ class LrUpdaterHook(Hook):
 
     def before_run(self, runner):
         for group in runner.optimizer.param_groups:
-            group.setdefault("initial_lr", group["lr"])
+            if "initial_lr" not in group:
+                group["initial_lr"] = lr_value(group["lr"])      # (a plain number also when lr is a device tensor)
         self.base_lr = [group["initial_lr"] for group in runner.optimizer.param_groups]
 
     def before_train_epoch(self, runner):

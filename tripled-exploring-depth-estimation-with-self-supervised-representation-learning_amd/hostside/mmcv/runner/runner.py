@@ -70,7 +70,7 @@ class Runner:
     def current_lr(self):
         if self.optimizer is None:
             raise RuntimeError("lr is not applicable because optimizer does not exist.")
-        return [group["lr"] for group in self.optimizer.param_groups]
+        return [H.lr_value(group["lr"]) for group in self.optimizer.param_groups]
 
     def register_hook(self, hook, priority="NORMAL"):
         assert isinstance(hook, H.Hook)
@@ -156,7 +156,14 @@ class Runner:
             if flat is not None:
                 flat.load_optimizer_state_dict(_unwrap(self.model), ckpt["optimizer"])
             else:
+                # a device-side lr tensor (graph replay reads it) keeps its identity; the file's value is written into it
+                held = [g["lr"] if torch.is_tensor(g["lr"]) else None for g in self.optimizer.param_groups]
                 self.optimizer.load_state_dict(ckpt["optimizer"])
+                for group, t in zip(self.optimizer.param_groups, held):
+                    if t is not None:
+                        t.fill_(float(group["lr"]))
+                        t._host_value = float(group["lr"])
+                        group["lr"] = t
         self.logger.info("resumed epoch %d, iter %d", self.epoch, self.iter)
 
     def run(self, data_loaders, workflow, max_epochs, **kwargs):

@@ -25,6 +25,10 @@ def _device():
 #   flat_params    True with amp="bf16" on a HIP device, Adam without paramwise options -- the flat mixed-precision
 #                  parameter store (tripled_amd.flat_amp): one cast instead of ~500 per-weight casts per step, one
 #                  single-tensor Adam, gradient all-reduce on one flat buffer; checkpoints keep the reference's layout
+#   hip_graph      True on a HIP device with Adam without paramwise options -- the Runner replays the whole iteration
+#                  (forward, backward, gradient exchange, clip, Adam) from ONE HIP graph after ``graph_warmup_iters`` (3)
+#                  eager iterations (tripled_amd.step.RunnerIteration); the LR schedule, logging, checkpoints and the
+#                  evaluation hooks stay outside the graph
 _MODE = {"autocast": None}
 
 
@@ -50,19 +54,27 @@ def configure_execution(model, cfg, dev):
     return model
 
 
-def change_input_variable(data):
-    """reference :19-29: every entry of the batch dict -> float32 on the training device.  The
-    copies are issued non-blocking (they are asynchronous when the loader pins memory)."""
+def stage_inputs(data):
+    """Every entry of the batch dict -> float32 on the training device (frames of the 'uint8' wire format stay bytes).
+    The copies are issued non-blocking (asynchronous when the loader pins memory; no-ops behind DevicePrefetcher)."""
     dev = _device()
+    for k, v in data.items():
+        if isinstance(k, tuple) and k and k[0] == "color_u8":       # 'uint8' wire format: bytes until expanded on the device
+            data[k] = torch.as_tensor(v).to(dev, non_blocking=True)
+        elif "kp" not in k:
+            data[k] = torch.as_tensor(v).to(dev, dtype=torch.float32, non_blocking=True)
+    return data
+
+
+def change_input_variable(data):
+    """reference :19-29: every entry of the batch dict -> float32 on the training device, then the device-side
+    expansion of the uint8 wire format."""
     if isinstance(data, dict):
-        for k, v in data.items():
-            if isinstance(k, tuple) and k and k[0] == "color_u8":       # 'uint8' wire format: bytes until expanded on the device
-                data[k] = torch.as_tensor(v).to(dev, non_blocking=True)
-            elif "kp" not in k:
-                data[k] = torch.as_tensor(v).to(dev, dtype=torch.float32, non_blocking=True)
+        stage_inputs(data)
         from mono.datasets import expand_device_batch
         expand_device_batch(data)
     else:
+        dev = _device()
         data[0] = [torch.as_tensor(img).to(dev, dtype=torch.float32, non_blocking=True) for img in data[0]]
     return data
 
@@ -159,11 +171,44 @@ def _build_flat_store(model, cfg):
     return flat, FlatOptimizerHook(flat, **cfg.optimizer_config)
 
 
+def _use_hip_graph(cfg, dev):
+    ocfg = cfg.optimizer
+    default = dev.type == "cuda" and ocfg.get("type") == "Adam" and ocfg.get("paramwise_options") is None
+    return bool(cfg.get("hip_graph", default))
+
+
+def _graphed_iteration(model, cfg, dev, flat, logger=None):
+    """(batch_processor, optimizer, optimiser hook) of a run whose iteration is replayed from a HIP graph."""
+    from tripled_amd.step import RunnerIteration, TrainStep
+    from mono.core import IterationDoneHook
+    from mono.datasets import expand_device_batch
+    step = TrainStep(model, cfg, None, _MODE["autocast"], flat=flat if flat is not None else False,
+                     prepare=expand_device_batch, device=dev, lr_tensor=True, keep_outputs=False)
+    iteration = RunnerIteration(step, stage_inputs, batch_processor, warmup_iters=cfg.get("graph_warmup_iters", 3),
+                                logger=logger, syncbn=bool(cfg.get("syncbn", False)) and _world_size() > 1)
+    return iteration, step.optimizer, IterationDoneHook(iteration, **cfg.optimizer_config)
+
+
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _loaders(dataset_train, cfg, dist):
+    """The training loader.  A dataset object may bring its own loader (``as_loader``): bench.py's HBM-resident batches
+    go through the Runner that way."""
+    if hasattr(dataset_train, "as_loader"):
+        return [dataset_train.as_loader(cfg.imgs_per_gpu)]
+    if dist:
+        return [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, dist=True)]
+    return [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, len(cfg.gpus), dist=False)]
+
+
 def _maybe_prefetch(loaders, cfg):
     """Overlap the host->device copy of batch t+1 with step t (cfg.device_prefetch, default on with a GPU)."""
     if torch.cuda.is_available() and cfg.get("device_prefetch", True):
         from mono.datasets import DevicePrefetcher
-        return [DevicePrefetcher(dl) for dl in loaders]
+        return [dl if getattr(dl, "device_resident", False) else DevicePrefetcher(dl) for dl in loaders]
     return loaders
 
 
@@ -177,7 +222,7 @@ def _finish_runner(runner, cfg, data_loaders):
 
 
 def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
-    data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, dist=True)]
+    data_loaders = _loaders(dataset_train, cfg, dist=True)
     dev = _device()
     if cfg.get("syncbn", False):
         # this build's BatchNorm layers exchange their statistics themselves (hand-written passes + one small
@@ -185,16 +230,21 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
         from mono.model.networks import enable_sync_batchnorm
         enable_sync_batchnorm(model)
     model = configure_execution(model, cfg, dev)
-    use_flat = _use_flat_store(cfg, dev)
+    use_flat, use_graph = _use_flat_store(cfg, dev), _use_hip_graph(cfg, dev)
+    # under graph replay Python autograd hooks do not run: the bucket engine then exchanges after backward (overlap=False:
+    # captured with the step on RCCL, eager between two graphs otherwise)
     model = MMDistributedDataParallel(model, find_unused_parameters=cfg.get("find_unused_parameters", False),
                                       device_ids=[dev.index] if dev.type == "cuda" else None,
-                                      broadcast_buffers=False, gradient_engine=not use_flat)
+                                      broadcast_buffers=False, gradient_engine=not use_flat, overlap=not use_graph)
+    flat, processor = None, batch_processor
     if use_flat:      # the store all-reduces its own flat gradient buffer; the wrapper only broadcasts the initial state
         flat, opt_hook = _build_flat_store(model, cfg)
         optimizer = flat.optimizer
-    else:
+    elif not use_graph:
         optimizer, opt_hook = build_optimizer(model, cfg.optimizer), DistOptimizerHook(**cfg.optimizer_config)
-    runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
+    if use_graph:
+        processor, optimizer, opt_hook = _graphed_iteration(model, cfg, dev, flat)
+    runner = Runner(model, processor, optimizer, cfg.work_dir, cfg.log_level)
     runner.register_training_hooks(cfg.lr_config, opt_hook, cfg.checkpoint_config, cfg.log_config)
     runner.register_hook(DistSamplerSeedHook())
     if validate:
@@ -205,14 +255,19 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
 
 
 def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False):
-    data_loaders = [build_dataloader(dataset_train, cfg.imgs_per_gpu, cfg.workers_per_gpu, len(cfg.gpus), dist=False)]
-    model = MMDataParallel(configure_execution(model, cfg, _device()), device_ids=list(range(len(cfg.gpus))))
-    if _use_flat_store(cfg, _device()):
+    data_loaders = _loaders(dataset_train, cfg, dist=False)
+    dev = _device()
+    model = MMDataParallel(configure_execution(model, cfg, dev), device_ids=list(range(len(cfg.gpus))))
+    use_graph = _use_hip_graph(cfg, dev)
+    flat, processor = None, batch_processor
+    if _use_flat_store(cfg, dev):
         flat, opt_hook = _build_flat_store(model, cfg)
         optimizer = flat.optimizer
-    else:
+    elif not use_graph:
         optimizer, opt_hook = build_optimizer(model, cfg.optimizer), cfg.optimizer_config
-    runner = Runner(model, batch_processor, optimizer, cfg.work_dir, cfg.log_level)
+    if use_graph:
+        processor, optimizer, opt_hook = _graphed_iteration(model, cfg, dev, flat)
+    runner = Runner(model, processor, optimizer, cfg.work_dir, cfg.log_level)
     runner.register_training_hooks(cfg.lr_config, opt_hook, cfg.checkpoint_config, cfg.log_config)
     if validate:
         if "num_classes" in cfg:

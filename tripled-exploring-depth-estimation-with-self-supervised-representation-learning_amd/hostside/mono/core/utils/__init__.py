@@ -1,1 +1,1 @@
-from .dist_utils import DistOptimizerHook, FlatOptimizerHook, allreduce_grads  # noqa: F401
+from .dist_utils import DistOptimizerHook, FlatOptimizerHook, IterationDoneHook, allreduce_grads  # noqa: F401

@@ -91,3 +91,17 @@ class FlatOptimizerHook(OptimizerHook):
         self.flat.collect()
         self.flat.allreduce()
         self.flat.step()
+
+
+class IterationDoneHook(OptimizerHook):
+    """The optimiser hook's slot when the Runner's batch_processor is ``tripled_amd.step.RunnerIteration``: zero_grad,
+    backward, gradient exchange, clip and step (reference: dist_utils.py:54-60) have already executed as part of the
+    replayed HIP graph when ``after_train_iter`` comes, so nothing is left to do here.  The LR schedule still acts in
+    ``before_train_iter`` (on the optimiser's device-side ``lr`` tensor), i.e. before the iteration, as in the reference."""
+
+    def __init__(self, iteration, grad_clip=None, **_unused):
+        self.iteration = iteration
+        self.grad_clip = grad_clip
+
+    def after_train_iter(self, runner):
+        pass

@@ -97,3 +97,45 @@ def synthetic_batch(batch_size, height, width, seed=1000, device=None, **kw):
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}
     return batch
+
+
+class ResidentBatches:
+    """``n_iters`` iterations over ONE batch that already sits in device memory, shaped like a loader (``len``,
+    iteration, ``sampler``) and like a dataset that brings its own loader (``as_loader``; mono.apis.trainer).  It is how
+    bench.py drives the Runner path (``train_mono``) with the inputs resident in HBM, as the metric prescribes."""
+    device_resident = True
+    sampler = None
+
+    def __init__(self, batch, n_iters, timed_from=None):
+        """``timed_from``: iterations ``timed_from .. n_iters-1`` are timed (device-synchronised, barrier across the ranks,
+        on both sides); the generator resumes after an iteration's hooks have run, so the bracket covers whole Runner
+        iterations.  ``elapsed`` (seconds) and ``timed_iters`` are set when the epoch ends."""
+        self.batch, self.n_iters = batch, int(n_iters)
+        self.timed_from, self.elapsed, self.timed_iters = timed_from, None, 0
+
+    def as_loader(self, imgs_per_gpu):
+        if int(self.batch["K"].shape[0]) != int(imgs_per_gpu):
+            raise ValueError("resident batch holds %d samples, the config asks for %d per GPU" % (self.batch["K"].shape[0], imgs_per_gpu))
+        return self
+
+    def __len__(self):
+        return self.n_iters
+
+    def _fence(self):
+        import time
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def __iter__(self):
+        t0 = None
+        for i in range(self.n_iters):
+            if self.timed_from is not None and i == self.timed_from:
+                t0 = self._fence()
+            yield dict(self.batch)
+        if t0 is not None:
+            self.elapsed = self._fence() - t0
+            self.timed_iters = self.n_iters - self.timed_from

@@ -1,12 +1,27 @@
 """One training iteration as a replayable unit: ``TrainStep`` (what the Runner's batch_processor +
 DistOptimizerHook do per iteration, reference: mono/apis/trainer.py:32-60,
-mono/core/utils/dist_utils.py:54-60) and ``capture_step`` (the same iteration recorded once into a
-HIP graph and replayed).  ``bench.py``, the training shim and the parity tests all go through this
-module, so the configuration that is benchmarked is the configuration that is tested.
+mono/core/utils/dist_utils.py:54-60), ``capture_step`` (the same iteration recorded once into a
+HIP graph and replayed) and ``RunnerIteration`` (the captured iteration behind the Runner's
+batch_processor slot: what ``train.py`` executes per batch, reference: mono/apis/trainer.py:147-189).
+``bench.py``, the training shim and the parity tests all go through this module, so the
+configuration that is benchmarked is the configuration that is tested and the one ``train.py`` runs.
 """
+import logging
 import math
+import os
+from collections import OrderedDict
 
 import torch
+import torch.distributed as dist
+
+
+def single_stream_capture_ok():
+    """A capture on ONE stream makes the step a linear graph, which ROCm 7.2 replays through its AQL-packet-capture
+    fast path -- wrongly for this step from the second replay on -- unless
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was in the environment when the HIP runtime initialised.  The package records on
+    import whether that was the case (``tripled_amd.PACKET_CAPTURE_OFF_AT_HIP_INIT``)."""
+    import tripled_amd
+    return bool(getattr(tripled_amd, "PACKET_CAPTURE_OFF_AT_HIP_INIT", False))
 
 
 class NonFiniteLossError(RuntimeError):
@@ -20,8 +35,14 @@ class TrainStep:
     ``outputs`` (the model's outputs dict) refer to the tensors of the last executed iteration; under
     graph replay they are the graph's static tensors and are refreshed by every replay."""
 
-    def __init__(self, model, cfg, batch, autocast_dtype, flat=False):
+    def __init__(self, model, cfg, batch, autocast_dtype, flat=False, prepare=None, device=None, lr_tensor=False,
+                 keep_outputs=True):
+        """``flat``: False (per-parameter fused Adam), "lowp" / "fp32" (a new flat store of that kind) or an existing
+        ``FlatMixedPrecision`` (the trainer's, which the checkpoint shim also knows).  ``prepare``: applied to a shallow
+        copy of the batch dict before the forward (the device-side expansion of the uint8 wire format).  ``lr_tensor``:
+        keep the learning rate in a device tensor, so that a schedule can change it under graph replay."""
         self.model, self.batch, self.dtype = model, batch, autocast_dtype
+        self.prepare, self.keep_outputs = prepare, keep_outputs
         inner = model.module if hasattr(model, "module") else model
         self.params = [p for p in inner.parameters() if p.requires_grad]
         ocfg = dict(cfg.optimizer)
@@ -31,14 +52,25 @@ class TrainStep:
         self.max_norm = clip["max_norm"] if clip else None
         self.reducer = getattr(model, "reducer", None)
         self.flat = None
-        on_gpu = batch["K"].is_cuda
-        if flat:
+        self.device = torch.device(device) if device is not None else batch["K"].device
+        on_gpu = self.device.type == "cuda"
+        if flat is not False and flat is not None and not isinstance(flat, str):
+            self.flat = flat
+            self.flat.max_norm = self.max_norm
+            self.optimizer = self.flat.optimizer
+        elif flat:
             from .flat_amp import FlatMixedPrecision
             self.flat = FlatMixedPrecision(inner, max_norm=self.max_norm, lowp=flat == "lowp", **ocfg)
             self.optimizer = self.flat.optimizer
         else:
             # fused multi-tensor Adam on the GPU (same update rule as torch.optim.Adam(lr, weight_decay=0))
             self.optimizer = torch.optim.Adam(self.params, capturable=on_gpu, fused=on_gpu, **ocfg)
+        if lr_tensor and on_gpu:
+            for group in self.optimizer.param_groups:
+                if not torch.is_tensor(group["lr"]):
+                    exact = float(group["lr"])
+                    group["lr"] = torch.tensor(exact, dtype=torch.float32, device=self.device)
+                    group["lr"]._host_value = exact      # what schedules and log lines read (mmcv.runner.hooks.lr_value)
         self.loss = None
         self.losses = {}
         self.outputs = {}
@@ -49,17 +81,20 @@ class TrainStep:
             self.flat.zero_grad()
         elif self.reducer is None:
             self.optimizer.zero_grad(set_to_none=True)   # with the DP engine, forward() re-zeroes the flat buffer
-        with torch.autocast("cuda" if self.batch["K"].is_cuda else "cpu", dtype=self.dtype,
-                            enabled=self.dtype is not None):
-            outputs, losses = self.model(dict(self.batch))
-        means = {k: v.float().mean() for k, v in losses.items()}
+        data = dict(self.batch)
+        if self.prepare is not None:
+            data = self.prepare(data)
+        with torch.autocast(self.device.type, dtype=self.dtype, enabled=self.dtype is not None):
+            outputs, losses = self.model(data)
+        means = OrderedDict((k, v.float().mean()) for k, v in losses.items())
         total = sum(means.values())
         total.backward()
         if self.flat is not None:
             self.flat.collect()
         self.loss = total.detach()
-        self.losses = {k: v.detach() for k, v in means.items()}
-        self.outputs = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in outputs.items()}
+        self.losses = OrderedDict((k, v.detach()) for k, v in means.items())
+        self.outputs = ({k: (v.detach() if torch.is_tensor(v) else v) for k, v in outputs.items()}
+                        if self.keep_outputs else {})
 
     def sync(self):
         if self.flat is not None:
@@ -132,6 +167,10 @@ def capture_step(step, stream=None, split=False, capture_error_mode="global", va
     step whose loss or parameters are not finite raises (ROCm 7.2 replayed a single-stream capture of this
     step wrongly from the SECOND replay on; tests/test_hip_graph_step.py compares the
     replayed trajectory with the eager one)."""
+    if stream is not None and not single_stream_capture_ok():
+        raise RuntimeError("single-stream capture needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the HIP "
+                           "runtime initialises (import tripled_amd before the first torch.cuda call, or export it): with the "
+                           "runtime's packet-capture fast path on, replays of this step are wrong from the second one on")
     graph = torch.cuda.CUDAGraph()
     graph_b = None
     if not split:
@@ -149,3 +188,149 @@ def capture_step(step, stream=None, split=False, capture_error_mode="global", va
         torch.cuda.synchronize()
         step.check_finite("replay %d of the captured step" % i)
     return g
+
+
+class RunnerIteration:
+    """The training iteration of ``train.py`` as a HIP-graph replay, in the Runner's ``batch_processor`` slot.
+
+    ``runner.train`` (mmcv 0.4.4: before_train_iter hooks -> batch_processor -> after_train_iter hooks, reference:
+    mono/apis/trainer.py:147-189) calls this object once per batch.  A call
+
+      1. moves the batch to the device (``stage``, normally a no-op behind DevicePrefetcher) and copies it into STATIC input
+         buffers (first batch: allocated from it).  The uint8 wire format stays bytes there; ``td_color_jitter`` runs inside
+         the step;
+      2. executes the whole iteration -- zero-grad, forward, sum of loss means, backward, gradient exchange, clip, Adam
+         (``TrainStep``) -- eagerly for the first ``warmup_iters`` batches (MIOpen picks its solvers, the allocator sizes its
+         pools; these are real training iterations on real batches), then captures it ONCE and from then on replays it;
+      3. returns ``dict(loss, log_vars, num_samples)`` like ``batch_processor``: ``log_vars`` are views of ONE snapshot of the
+         graph's static loss scalars (a single small copy per iteration; read back only when a log line is due).
+
+    The learning rate lives in a device tensor (``lr_tensor``), so ``LrUpdaterHook`` changes it between replays; the update
+    has already happened when the optimiser hook's slot comes, so the trainer registers ``IterationDoneHook`` there.  A
+    batch whose shapes differ from the static buffers (a ragged tail without drop_last) takes the eager iteration.  The
+    evaluation hooks run outside the graph.  N > 1: on RCCL the collectives (flat gradient all-reduce, SyncBatchNorm
+    statistics) are captured with the step; on a backend whose collectives cannot be captured the step is two graphs around
+    an eager all-reduce (no SyncBatchNorm) or eager.  Every rank takes the same decision (all_reduce(MIN) of the outcome).
+    """
+
+    def __init__(self, step, stage, eager_processor, warmup_iters=3, logger=None, syncbn=False):
+        self.step, self.stage, self.eager_processor = step, stage, eager_processor
+        self.warmup_iters = max(1, int(warmup_iters))
+        self.logger = logger or logging.getLogger(__name__)
+        self.syncbn = syncbn
+        self.static = None
+        self.signature = None
+        self.graphed = None
+        self.mode = None              # "one-graph" | "two-graph" | "eager" once decided
+        self.seen = 0
+        self.replays = 0
+        self.eager_iterations = 0
+        self.side = None
+        self._keys = None
+        self._snap_src = None
+
+    # ---- inputs --------------------------------------------------------------------------------------------
+    @staticmethod
+    def _sig(data):
+        return tuple((str(k), tuple(v.shape), v.dtype) for k, v in data.items() if torch.is_tensor(v))
+
+    def _load_static(self, data):
+        if self.static is None:
+            self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+            self.signature = self._sig(self.static)
+            self.step.batch = self.static
+            return True
+        if self._sig(data) != self.signature:
+            return False
+        for k, v in data.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+        return True
+
+    # ---- execution modes -----------------------------------------------------------------------------------
+    def _world(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _candidate_modes(self):
+        if self._world() == 1:
+            return ["one-graph", "eager"]
+        if dist.get_backend() == "nccl":
+            return ["one-graph"] + ([] if self.syncbn else ["two-graph"]) + ["eager"]
+        return ([] if self.syncbn else ["two-graph"]) + ["eager"]
+
+    def _agree(self, ok):
+        if self._world() == 1:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.step.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0)
+
+    def _capture(self):
+        stream = self.side if single_stream_capture_ok() else None
+        dp = self._world() > 1
+        for mode in self._candidate_modes():
+            if mode == "eager":
+                self.mode, self.graphed = "eager", None
+                break
+            ok, g = True, None
+            try:
+                if dp:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                g = capture_step(self.step, stream=stream, split=mode == "two-graph",
+                                 capture_error_mode="thread_local" if dp else "global", validate=False)
+            except Exception as e:      # noqa: BLE001 -- this form is not available here; the next one is tried
+                ok = False
+                self.logger.warning("HIP-graph capture of the training iteration (%s) failed: %s: %s", mode, type(e).__name__,
+                                    str(e)[:300])
+            if self._agree(ok):
+                self.mode, self.graphed = mode, g
+                break
+        self.logger.info("training iteration: %s%s", self.mode,
+                         "" if self.graphed is None else " (captured on %s)" % ("one stream" if stream is not None
+                                                                              else "the default capture stream"))
+
+    def _run_eager(self):
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        warm_up(self.step, 1, self.side) if self.mode is None else self.step()
+        self.eager_iterations += 1
+
+    # ---- the batch_processor call --------------------------------------------------------------------------
+    def __call__(self, model, data, train_mode, **kwargs):
+        if not train_mode:
+            return self.eager_processor(model, data, train_mode, **kwargs)
+        model.train()
+        data = self.stage(data)
+        n = int(data["K"].shape[0])
+        if not self._load_static(data):
+            # a batch of another shape: the same iteration, eagerly, on that batch
+            self.step.batch = data
+            try:
+                self.step()
+            finally:
+                self.step.batch = self.static
+            self.eager_iterations += 1
+            return self._result(n)
+        self.seen += 1
+        if self.mode is None and self.seen <= self.warmup_iters:
+            self._run_eager()
+            return self._result(n)
+        if self.mode is None:
+            self._capture()
+        if self.graphed is None:
+            self._run_eager()
+            return self._result(n)
+        self.graphed()
+        self.replays += 1
+        if self.replays <= 2:       # the health gate of capture_step, on the first real replays (host sync, twice)
+            torch.cuda.synchronize()
+            self.step.check_finite("replay %d of the captured training iteration" % self.replays)
+        return self._result(n)
+
+    def _result(self, n):
+        losses = self.step.losses
+        keys = [str(k) for k in losses] + ["loss"]
+        snap = torch.stack([v.reshape(()) for v in losses.values()] + [self.step.loss.reshape(())])
+        log_vars = OrderedDict((k, snap[i]) for i, k in enumerate(keys))
+        return dict(loss=self.step.loss, log_vars=log_vars, num_samples=n)
