@@ -242,6 +242,28 @@ int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const flo
               float* dgamma, float* dbeta, float* workspace, td_stream_t stream);
 
 /*
+ * 1x1 convolution of the ResNet bottlenecks on channels-last bf16 activations as an MFMA GEMM
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulation) whose epilogue forms the partial batch statistics of the
+ * BatchNorm that follows it.  Replaces nn.Conv2d(kernel_size=1) + the statistics pass of nn.BatchNorm2d in
+ * Bottleneck.forward (mono/model/mono_fm_joint/resnet.py:66-86: conv1 -> bn1, conv3 -> bn3) and in the strided
+ * 1x1 down-sample branch (resnet.py:119-127).
+ *   x [rows_in, K] bf16 (rows_in = M for stride 1; N_img*Hi*Wi for the strided form), w [N, K] bf16 (the [N,K,1,1] weight),
+ *   y [M, N] bf16, M = output pixels; K % 64 == 0, N % 64 == 0; groups: M is `groups` consecutive equal row ranges with
+ *   separate statistics (stacked passes, as td_bn_fwd).
+ *   stat_partials (may be NULL): [groups, S, N, 2] f32 with S = td_conv1x1_stat_rows(M, groups, N): (sum y, sum y^2) over the
+ *   rows of each row tile, of the bf16-rounded outputs -- the layout td_bn_fwd_from_partials consumes.
+ * td_bn_fwd_from_partials: td_bn_fwd without its statistics pass (finalize + apply): mean / invstd / running statistics
+ *   from `partials` [groups, stat_rows, C, 2], then y = relu?( (x - mean) * invstd * gamma + beta [+ residual] ).
+ */
+int td_conv1x1_stat_rows(long long M, int groups, int N);
+int td_conv1x1_fwd(const void* x, const void* w, long long M, int groups, int K, int N, int Hi, int Wi, int stride, void* y,
+                   float* stat_partials, td_stream_t stream);
+int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
+                            int groups, int C, const float* partials, int stat_rows, void* y, float* save_mean,
+                            float* save_invstd, td_stream_t stream);
+
+/*
  * The same normalisation with statistics synchronised over the data-parallel ranks (the reference trains with
  * syncbn=True: torch.nn.SyncBatchNorm.convert_sync_batchnorm, mono/apis/trainer.py:156-157).  The caller
  * all-reduces (SUM) the [groups, C, 2] per-channel sums and the row count between the two stages; everything

@@ -104,16 +104,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partials_kernel(const T* __rest
   }
 }
 
-// sums the S partials of one 64-channel group; result (sumA, sumB) valid in threads 0..63
-constexpr int BN_FIN_PARTS = 16;                      // finalize block: 64 channels x 16 slices of the S partials
-constexpr int BN_FIN_THREADS = 64 * BN_FIN_PARTS;
+// sums the S partials of one BN_FIN_CH-channel group; result (sumA, sumB) valid in threads 0..BN_FIN_CH-1.
+// 16 channels per block (128 contiguous bytes per partial row): a 64-channel layer still gets 4 blocks and a 2048-channel one
+// 128, where one block per 64 channels left the finalize of the wide layers on 1..32 CUs, latency-bound at ~6 us.
+constexpr int BN_FIN_CH = 16;
+constexpr int BN_FIN_PARTS = 16;                      // finalize block: 16 channels x 16 slices of the S partials
+constexpr int BN_FIN_THREADS = BN_FIN_CH * BN_FIN_PARTS;
 __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, int S, int C, int cg, float& A, float& B) {
-  __shared__ float red[2][BN_FIN_PARTS][64];
-  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  __shared__ float red[2][BN_FIN_PARTS][BN_FIN_CH];
+  const int tid = threadIdx.x, c = tid % BN_FIN_CH, part = tid / BN_FIN_CH;
   float a = 0.f, b = 0.f;
 #pragma unroll 4
   for (int s = part; s < S; s += BN_FIN_PARTS) {
-    const float2 p = *reinterpret_cast<const float2*>(ws + ((size_t)s * C + (size_t)cg * 64 + c) * 2);
+    const float2 p = *reinterpret_cast<const float2*>(ws + ((size_t)s * C + (size_t)cg * BN_FIN_CH + c) * 2);
     a += p.x;
     b += p.y;
   }
@@ -122,7 +125,7 @@ __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, in
   __syncthreads();
   A = 0.f;
   B = 0.f;
-  if (tid < 64) {
+  if (tid < BN_FIN_CH) {
 #pragma unroll
     for (int j = 0; j < BN_FIN_PARTS; ++j) { A += red[0][j][c]; B += red[1][j][c]; }
   }
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_fwd_kernel(const f
   for (int grp = 0; grp < G; ++grp) {
     float A, B;
     bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
-    if (threadIdx.x < 64) {
-      const int c = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < BN_FIN_CH) {
+      const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
       const double m = (double)A / (double)M;
       double var = (double)B / (double)M - m * m;      // biased variance, formed in double
       var = var > 0.0 ? var : 0.0;
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_reduce_partials_kernel(cons
   for (int grp = 0; grp < G; ++grp) {
     float A, B;
     bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
-    if (threadIdx.x < 64) {
-      const size_t c = (size_t)grp * C + blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < BN_FIN_CH) {
+      const size_t c = (size_t)grp * C + blockIdx.x * BN_FIN_CH + threadIdx.x;
       sums[c * 2 + 0] = A;
       sums[c * 2 + 1] = B;
     }
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_bwd_kernel(const f
   for (int grp = 0; grp < G; ++grp) {
     float A, B;
     bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
-    if (threadIdx.x < 64) {
-      const int c = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < BN_FIN_CH) {
+      const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
       const float is = invstd[(size_t)grp * C + c], mu = mean[(size_t)grp * C + c];
       const float dg = B * is;                     // sum g * xhat
       dg_tot += dg;
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_bwd_kernel(const f
     }
     __syncthreads();
   }
-  if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < BN_FIN_CH) {
+    const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
     dgamma[c] = dg_tot;
     dbeta[c] = db_tot;
   }
@@ -387,7 +390,7 @@ static int run_bn_fwd(const void* x, const void* res, const float* gamma, const 
   const int S_eff = (int)((Mg + rps - 1) / rps);
   hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
                      (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C, rps, 0, ws);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, eps, momentum,
                      rmean, rvar, save_mean, save_invstd);
   const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)x,
@@ -404,7 +407,7 @@ static int run_bn_bwd(const void* dy, const void* x, const void* y, const float*
   float* coef = ws + (size_t)2 * S_eff * C * G;
   hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                      (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, gamma, mean,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, gamma, mean,
                      invstd, dgamma, dbeta, coef);
   const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
   hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)dy,
@@ -427,7 +430,7 @@ static int run_bn_local_sums(int mode, const void* x, const void* dy, const void
   else
     hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                        (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C / 64), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, G, sums);
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, G, sums);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
@@ -498,6 +501,33 @@ extern "C" int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype
     return td::run_bn_bwd<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, dx, dresidual, dgamma, dbeta, workspace,
                                  (hipStream_t)stream);
   return TD_ERR_UNSUPPORTED;
+}
+
+// Forward with the partial sums already formed by the producing kernel (td_conv1x1_fwd's epilogue): finalize + apply,
+// two launches instead of three and no statistics pass over x.  partials: [groups, stat_rows, C, 2] f32.
+extern "C" int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
+                                       int groups, int C, const float* partials, int stat_rows, void* y, float* save_mean,
+                                       float* save_invstd, td_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !partials || stat_rows < 1 || !bn_shape_ok(M, groups, C))
+    return TD_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TD_ERR_BAD_ARG;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype != TD_DTYPE_BF16 && dtype != TD_DTYPE_F32) return TD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const long long Mg = M / groups;
+  hipLaunchKernelGGL(td::bn_finalize_fwd_kernel, dim3(C / td::BN_FIN_CH), dim3(td::BN_FIN_THREADS), 0, st, partials, stat_rows, C, Mg, groups, eps,
+                     momentum, running_mean, running_var, save_mean, save_invstd);
+  const int S2 = td::bn_splits(Mg, C, 2048 / groups, 4096), rps2 = td::bn_rows_per_split(Mg, S2);
+  const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), groups);
+  if (dtype == TD_DTYPE_BF16)
+    hipLaunchKernelGGL((td::bn_apply_kernel<__hip_bfloat16>), grid, dim3(td::BN_THREADS), 0, st, (const __hip_bfloat16*)x,
+                       (const __hip_bfloat16*)residual, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2,
+                       relu, (__hip_bfloat16*)y);
+  else
+    hipLaunchKernelGGL((td::bn_apply_kernel<float>), grid, dim3(td::BN_THREADS), 0, st, (const float*)x, (const float*)residual, gamma,
+                       beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (float*)y);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
 // ---- synchronised (cross-rank) statistics: local sums -> [caller: all-reduce] -> apply / dx --------------------

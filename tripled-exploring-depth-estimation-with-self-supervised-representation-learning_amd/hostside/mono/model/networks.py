@@ -61,9 +61,11 @@ class BatchNorm(nn.BatchNorm2d):
     _pending = 0
     _sync = None            # (process_group,) when the batch statistics span the data-parallel ranks (enable_sync_batchnorm)
 
+    def _hip_ok_params(self):
+        return bool(self.training and self.track_running_stats and self.momentum is not None and self.affine) and not FUSED_BN_OFF
+
     def _hip_ok(self, x):
-        if not (x.is_cuda and self.training and self.track_running_stats and self.momentum is not None
-                and self.affine) or FUSED_BN_OFF:
+        if not (x.is_cuda and self._hip_ok_params()):
             return False
         return _ops().batchnorm_act_supported(x, self.weight)
 
@@ -213,6 +215,27 @@ def bn_act(bn, x, residual=None, relu=True):
     return _plain_bn_act(bn, x, residual, relu)
 
 
+FUSED_1X1_OFF = bool(os.environ.get("TD_NO_MFMA_1X1"))
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=True):
+    """conv -> bn -> [+ residual] -> [relu].  A 1x1 convolution (stride 1 or the stride-2 down-sample branch) in front of this
+    build's BatchNorm on bf16 channels_last HIP activations runs as the hand-written MFMA GEMM whose epilogue forms the batch
+    statistics (tripled_amd.ops.conv1x1_bn_act: csrc/td_conv1x1.hip); everything else takes conv (MIOpen) + bn_act."""
+    if (not FUSED_1X1_OFF and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None
+            and conv.stride[0] == conv.stride[1] and isinstance(bn, BatchNorm) and bn._sync is None and not _FP8_1X1[0]
+            and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+            and bn._hip_ok_params()):
+        xb = _dense_cl(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
+        w = conv.weight if conv.weight.dtype == torch.bfloat16 else conv.weight.to(torch.bfloat16)
+        if _ops().conv1x1_bn_act_supported(xb, w, bn.weight, conv.stride[0]):
+            g = _BN_GROUPS[0]
+            bn._pending += g
+            return _ops().conv1x1_bn_act(xb, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                         residual=residual, relu=relu, groups=g, stride=conv.stride[0])
+    return bn_act(bn, conv(x), residual, relu)
+
+
 def bump_batch_counters(model):
     """num_batches_tracked += (forward calls since the last bump) for every BatchNorm of ``model``,
     as one multi-tensor add."""
@@ -288,7 +311,13 @@ class BasicBlock(nn.Module):
         y = bn_act(self.bn1, self.conv1(x))
         shortcut = None
         if self.use_residual:
-            shortcut = x if self.downsample is None else self.downsample(x)
+            ds = self.downsample
+            if ds is None:
+                shortcut = x
+            elif isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
+                shortcut = conv_bn_act(ds[0], ds[1], x, relu=False)      # 1x1 stride-2 branch: MFMA GEMM + epilogue statistics
+            else:
+                shortcut = ds(x)
         return bn_act(self.bn2, self.conv2(y), shortcut)
 
 
@@ -308,10 +337,18 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def _shortcut(self, x):
+        ds = self.downsample
+        if ds is None:
+            return x
+        if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d):
+            return conv_bn_act(ds[0], ds[1], x, relu=False)
+        return ds(x)
+
     def forward(self, x):
-        y = bn_act(self.bn1, self.conv1(x))
+        y = conv_bn_act(self.conv1, self.bn1, x)
         y = bn_act(self.bn2, self.conv2(y))
-        return bn_act(self.bn3, self.conv3(y), x if self.downsample is None else self.downsample(x))
+        return conv_bn_act(self.conv3, self.bn3, y, self._shortcut(x))
 
 
 class ResNet(nn.Module):

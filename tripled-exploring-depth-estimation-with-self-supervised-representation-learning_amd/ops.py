@@ -376,6 +376,80 @@ class _BatchNormAct(torch.autograd.Function):
         return dx, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None, None
 
 
+class _Conv1x1BatchNormAct(torch.autograd.Function):
+    """relu?( batch_norm( conv1x1(x, w) ) [+ residual] ) with the convolution on the hand-written MFMA GEMM and the batch
+    statistics taken from its epilogue (no statistics pass over the convolution output): three launches -- GEMM, finalize,
+    apply.  Backward: td_bn_bwd, then the convolution's data / weight gradients through ATen (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, w, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, stride):
+        lib = native.load()
+        Nb, K, Hi, Wi = x.shape
+        N = w.shape[0]
+        Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+        M = Nb * Ho * Wo
+        yc = torch.empty((Nb, N, Ho, Wo), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        S = lib.td_conv1x1_stat_rows(M, groups, N)
+        part = torch.empty(groups * S * N * 2, device=x.device, dtype=torch.float32)
+        native.check(lib.td_conv1x1_fwd(_raw(x), _raw(w), M, groups, K, N, Hi, Wi, stride, _raw(yc), native.ptr(part),
+                                        native.stream()), "td_conv1x1_fwd")
+        y = torch.empty_like(yc, memory_format=torch.channels_last)
+        mean = torch.empty(groups * N, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(groups * N, device=x.device, dtype=torch.float32)
+        native.check(lib.td_bn_fwd_from_partials(_raw(yc), _raw(residual) if residual is not None else None,
+                                                 native.DTYPE_CODES[yc.dtype], native.ptr(weight), native.ptr(bias),
+                                                 native.ptr(running_mean) if running_mean is not None else None,
+                                                 native.ptr(running_var) if running_var is not None else None,
+                                                 float(momentum), float(eps), int(relu), M, groups, N, native.ptr(part), S, _raw(y),
+                                                 native.ptr(mean), native.ptr(invstd), native.stream()), "td_bn_fwd_from_partials")
+        ctx.save_for_backward(x, w, yc, y if (relu and residual is not None) else None, weight, bias, mean, invstd)
+        ctx.relu, ctx.has_res, ctx.groups, ctx.stride = bool(relu), residual is not None, groups, stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = native.load()
+        x, w, yc, y, weight, bias, mean, invstd = ctx.saved_tensors
+        Nb, N, Ho, Wo = yc.shape
+        M = Nb * Ho * Wo
+        if dy.dtype != yc.dtype or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(yc.dtype).contiguous(memory_format=torch.channels_last)
+        dyc = torch.empty_like(yc, memory_format=torch.channels_last)
+        dres = torch.empty_like(yc, memory_format=torch.channels_last) if (ctx.has_res and ctx.relu) else None
+        dgamma = torch.empty(N, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(N, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib.td_bn_workspace_floats(M, ctx.groups, N), device=x.device, dtype=torch.float32)
+        native.check(lib.td_bn_bwd(_raw(dy), _raw(yc), _raw(y) if y is not None else None, native.DTYPE_CODES[yc.dtype],
+                                   native.ptr(weight), native.ptr(bias), native.ptr(mean), native.ptr(invstd), int(ctx.relu), M,
+                                   ctx.groups, N, _raw(dyc), _raw(dres) if dres is not None else None, native.ptr(dgamma),
+                                   native.ptr(dbeta), native.ptr(ws), native.stream()), "td_bn_bwd")
+        if ctx.has_res and not ctx.relu:
+            dres = dy
+        dx, dw, _ = torch.ops.aten.convolution_backward(dyc, x, w, None, [ctx.stride, ctx.stride], [0, 0], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None, None, None
+
+
+def conv1x1_bn_act_supported(x, w, bn_weight, stride=1):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 4
+            and w.shape[2] == 1 and w.shape[3] == 1 and w.shape[1] == x.shape[1] and x.shape[1] % 64 == 0 and w.shape[0] % 64 == 0
+            and stride in (1, 2) and bn_weight is not None and bn_weight.dtype == torch.float32
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)))
+
+
+def conv1x1_bn_act(x, w, weight, bias, running_mean, running_var, momentum, eps, residual=None, relu=False, groups=1, stride=1):
+    """conv1x1 -> training-mode BatchNorm2d -> [+ residual] -> [relu] (reference: resnet.py:66-86 conv1/bn1, conv3/bn3 and the
+    down-sample branch :119-127) for bf16 channels_last HIP tensors, Cin % 64 == Cout % 64 == 0."""
+    if x.shape[0] % groups:
+        raise ValueError("batch %d is not %d stacked passes" % (x.shape[0], groups))
+    if not conv1x1_bn_act_supported(x, w, weight, stride):
+        raise native.NativeLibraryError("conv1x1_bn_act needs bf16 channels_last HIP tensors with Cin % 64 == Cout % 64 == 0")
+    if residual is not None and (residual.dtype != x.dtype or not residual.is_contiguous(memory_format=torch.channels_last)):
+        residual = residual.to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return _Conv1x1BatchNormAct.apply(x, w, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, stride)
+
+
 def batchnorm_act_supported(x, weight):
     return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 64 == 0
             and weight is not None and weight.dtype == torch.float32

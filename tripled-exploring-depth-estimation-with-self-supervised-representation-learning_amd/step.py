@@ -226,8 +226,7 @@ class RunnerIteration:
         self.replays = 0
         self.eager_iterations = 0
         self.side = None
-        self._keys = None
-        self._snap_src = None
+        self._graph_out = None
 
     # ---- inputs --------------------------------------------------------------------------------------------
     @staticmethod
@@ -285,6 +284,8 @@ class RunnerIteration:
                                     str(e)[:300])
             if self._agree(ok):
                 self.mode, self.graphed = mode, g
+                # the graph's own output tensors: an eager iteration in between (a ragged batch) rebinds step.loss / step.losses
+                self._graph_out = (self.step.loss, self.step.losses)
                 break
         self.logger.info("training iteration: %s%s", self.mode,
                          "" if self.graphed is None else " (captured on %s)" % ("one stream" if stream is not None
@@ -322,6 +323,7 @@ class RunnerIteration:
             self._run_eager()
             return self._result(n)
         self.graphed()
+        self.step.loss, self.step.losses = self._graph_out
         self.replays += 1
         if self.replays <= 2:       # the health gate of capture_step, on the first real replays (host sync, twice)
             torch.cuda.synchronize()
@@ -329,8 +331,8 @@ class RunnerIteration:
         return self._result(n)
 
     def _result(self, n):
-        losses = self.step.losses
+        loss, losses = self.step.loss, self.step.losses
         keys = [str(k) for k in losses] + ["loss"]
-        snap = torch.stack([v.reshape(()) for v in losses.values()] + [self.step.loss.reshape(())])
+        snap = torch.stack([v.reshape(()) for v in losses.values()] + [loss.reshape(())])     # one small copy per iteration
         log_vars = OrderedDict((k, snap[i]) for i, k in enumerate(keys))
-        return dict(loss=self.step.loss, log_vars=log_vars, num_samples=n)
+        return dict(loss=loss, log_vars=log_vars, num_samples=n)
