@@ -38,7 +38,7 @@ from mmcv import Config  # noqa: E402
 from mono.datasets.synthetic import synthetic_batch  # noqa: E402
 from mono.model import MONO  # noqa: E402
 from tripled_amd import dispatch  # noqa: E402
-from tripled_amd.step import NonFiniteLossError, TrainStep, capture_step, warm_up  # noqa: E402
+from tripled_amd.step import NonFiniteLossError, TrainStep, capture_step, ranks_agree, replicas_agree, warm_up  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 # algorithmic bytes per full-resolution pixel of one fused photometric launch at scale s
@@ -50,6 +50,36 @@ def photo_fwd_bytes_per_px(s):
 
 def photo_bwd_bytes_per_px(s):
     return 12 + 24 + 4.0 / 4 ** (s + 1) + 1 + 4.0 / 4 ** (s + 1)
+
+
+PKG = os.path.join(ROOT, "tripled-exploring-depth-estimation-with-self-supervised-representation-learning_amd")
+# what a committed PMC figure depends on: it is only quoted in the line while these sources (and the workload) are the ones
+# it was measured on (tools/traffic_from_pmc.py and tools/mfma_summary.py write the same stamp into the file)
+TRAFFIC_SOURCES = ["csrc/td_photo_fwd.hip", "csrc/td_photo_bwd.hip", "csrc/td_common.h"]
+MFMA_SOURCES = ["csrc/td_conv1x1.hip", "csrc/td_bn.hip", "hostside/mono/model/networks.py", "ops.py"]
+
+
+def source_stamp(files):
+    import hashlib
+    h = hashlib.sha256()
+    for rel in files:
+        with open(os.path.join(PKG, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def stamped(path, files, workload):
+    """The JSON at ``path`` if its ``_stamp`` matches the current sources and workload, else (None, reason)."""
+    if not os.path.exists(path):
+        return None, "no %s" % os.path.basename(path)
+    with open(path) as fh:
+        blob = json.load(fh)
+    st = blob.get("_stamp") or {}
+    if st.get("sources_sha16") != source_stamp(files):
+        return None, "%s was measured on other kernel sources (stamp %s)" % (os.path.basename(path), st.get("sources_sha16"))
+    if st.get("workload") != workload:
+        return None, "%s was measured on %s, this run is %s" % (os.path.basename(path), st.get("workload"), workload)
+    return blob, None
 
 
 def parse():
@@ -426,9 +456,7 @@ def main():
             ok = False
             print("rank %d: step mode %r unavailable (%s: %s)" % (rank, mode, type(e).__name__, str(e)[:300]), file=sys.stderr)
         if dp:
-            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item() > 0)
+            ok = ranks_agree(ok, dev)          # every rank runs the same step form (tests/test_dp_gloo.py)
         if ok:
             if cand["graphed"] is not None:
                 for i in range(2):      # validation replays (all ranks together): a captured step that is not finite is an error
@@ -452,11 +480,7 @@ def main():
     del candidates, base_model
     if dp and world > 1:
         # the replicas must hold identical parameters after the captured steps
-        chk = torch.stack([p_.detach().double().sum() for p_ in model.parameters()]).sum().reshape(1)
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if float(hi - lo) > 1e-6 * max(1.0, abs(float(hi))):
+        if not replicas_agree(model):
             raise SystemExit("bench.py: INVALID RUN: replicas diverged under step mode %r" % used_mode)
     split_graph = graphed and graphed_step.graph_b is not None
     use_flat = step.flat is not None
@@ -578,13 +602,12 @@ def main():
             kern = roofline_of_hot_kernels(cfg, batch)
             dom = max(kern, key=lambda k: kern[k]["seconds"])
             ach = kern[dom]["bytes"] / kern[dom]["seconds"] / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get(dom)
+            workload = "B=%d %dx%d n_src=%d" % (B, H, W, len(m["frame_ids"]) - 1)
+            tblob, why = stamped(os.path.join(ROOT, "profiles", "traffic.json"), TRAFFIC_SOURCES, workload)
+            traffic = tblob.get(dom) if tblob else None
             line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                "traffic_source": (tblob["_stamp"] if tblob else why),
                                 "launch_us": round(kern[dom]["seconds"] * 1e6, 2),
                                 "all": {k: {"us": round(v["seconds"] * 1e6, 2),
                                             "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in kern.items()}}
@@ -605,12 +628,14 @@ def main():
             line["roofline_conv"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS * world,
                                      "unit": "TFLOP/s", "frac": round(tf / (MFMA_BF16_PEAK_TFLOPS * world), 4),
                                      "what": "reference-algorithmic conv FLOPs (SURVEY section 6) / whole step time"}
-            mpath = os.path.join(ROOT, "profiles", "mfma.json")
-            if os.path.exists(mpath) and world == 1:
-                # PMC evidence (separate rocprofv3 --pmc pass, profiles/r02): MFMA-busy cycles of one step, summed over
+            mf, why = stamped(os.path.join(ROOT, "profiles", "mfma.json"), MFMA_SOURCES,
+                              "%s B=%d %dx%d" % (os.path.basename(args.config), B, H, W))
+            if mf is None:
+                line["roofline_conv"]["pmc"] = None
+                line["roofline_conv"]["pmc_note"] = why
+            elif world == 1:
+                # PMC evidence (separate rocprofv3 --pmc pass): MFMA-busy cycles of one step, summed over
                 # the 1024 SIMDs; one busy cycle = 1024 bf16 FLOP, so this is the EXECUTED matrix work of the step
-                with open(mpath) as f:
-                    mf = json.load(f)
                 busy = mf["mfma_busy_cycles_per_step"]
                 line["roofline_conv"]["pmc"] = {
                     "mfma_busy_frac_of_step": round(busy / (ms * 1e-3 * mf["clock_ghz"] * 1e9 * mf["simds"]), 4),

@@ -215,3 +215,40 @@ def _worker_syncbn(rank, world, port):
 def test_two_rank_sync_batchnorm():
     port = _free_port()
     mp.spawn(_worker_syncbn, args=(2, port), nprocs=2, join=True)
+
+
+def _worker_agreement(rank, world, port):
+    """The harness logic that keeps N > 1 runs honest (bench.py, tripled_amd.step.RunnerIteration): the ranks settle on ONE
+    step form (all_reduce(MIN) of each rank's outcome), the candidate order follows the backend and the config's syncbn, and
+    replicas whose parameters differ are detected on every rank."""
+    sys.path.insert(0, ROOT)
+    import tripled_amd  # noqa: F401
+    from tripled_amd.step import RunnerIteration, ranks_agree, replicas_agree
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mono.apis import init_dist
+    init_dist("pytorch", backend="gloo")
+    cpu = torch.device("cpu")
+    assert ranks_agree(True, cpu) is True
+    assert ranks_agree(rank == 0, cpu) is False            # a form that one rank could not bring up is dropped by all
+    assert ranks_agree(False, cpu) is False
+
+    class _Step:                                             # only what the mode logic touches
+        device = cpu
+    it = RunnerIteration(_Step(), lambda d: d, lambda *a, **k: None, syncbn=False)
+    assert it._candidate_modes() == ["two-graph", "eager"]   # gloo collectives cannot be captured: never "one-graph"
+    assert RunnerIteration(_Step(), lambda d: d, lambda *a, **k: None, syncbn=True)._candidate_modes() == ["eager"]
+    assert it._agree(rank == 1) is False and it._agree(True) is True
+
+    torch.manual_seed(3)
+    net = Net()
+    assert replicas_agree(net)
+    if rank == 1:
+        with torch.no_grad():
+            net.c.weight[0, 0] += 1e-3
+    assert not replicas_agree(net)                           # detected on BOTH ranks
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mode_agreement_and_replica_check():
+    mp.spawn(_worker_agreement, args=(2, _free_port()), nprocs=2, join=True)

@@ -189,3 +189,43 @@ def test_stereo_plus_temporal_frames_match_cpu_oracle():
         num += float((p.grad.cpu().double() - pc[n].grad.double()).pow(2).sum())
         den += float(pc[n].grad.double().pow(2).sum())
     assert (num / den) ** 0.5 < 3e-2
+
+
+def test_c4_shape_step_with_find_mode():
+    """BASELINE config 4 at the model level: cfg_kitti_tripleD_320x1024.py (4 images per GPU) with ResNet18 networks, bf16
+    autocast + channels_last, MIOpen find mode ON (cudnn_benchmark, as the config sets it) -- the mode in which the tuning search
+    of the 16-channel 3x3 layers faulted on inputs wider than 1024 columns: the guard
+    (networks._conv2d_guarded) must route those layers around the search, the step must run with zero ATen fallbacks and
+    finite loss / gradients, and the photometric kernels see the 320x1024 tiling end to end."""
+    import os
+    import tripled_amd  # noqa: F401
+    from mmcv import Config
+    from mono.datasets import synthetic_batch
+    from mono.model import MONO
+    from tripled_amd import dispatch
+    from tripled_amd.step import TrainStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "config", "cfg_kitti_tripleD_320x1024.py"))
+    cfg.model.update(depth_num_layers=18, pose_num_layers=18, extractor_num_layers=18)
+    m = cfg.model
+    assert (m["height"], m["width"], m["imgs_per_gpu"]) == (320, 1024, 4)
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        torch.manual_seed(1024)
+        dev = torch.device("cuda", 0)
+        model = MONO.module_dict[m["name"]](m).to(dev).to(memory_format=torch.channels_last).train()
+        batch = synthetic_batch(4, 320, 1024, seed=1000, device=dev, frame_ids=tuple(m["frame_ids"]))
+        step = TrainStep(model, cfg, batch, torch.bfloat16, flat="lowp")
+        dispatch.reset()
+        with dispatch.strict():
+            for _ in range(2):
+                step()
+        torch.cuda.synchronize()
+    finally:
+        torch.backends.cudnn.benchmark = prev
+    assert sum(dispatch.fallbacks.values()) == 0, dict(dispatch.fallbacks)
+    assert dispatch.hip_calls["td_photo_fwd"] == 2 * 4 and dispatch.hip_calls["td_photo_bwd"] == 2 * 4
+    step.check_finite("C4-shape step")
+    assert step.outputs[("disp", 0, 0)].shape == (4, 1, 320, 1024)
+    assert bool(torch.isfinite(step.flat.flat_g).all()) and float(step.flat.flat_g.abs().max()) > 0

@@ -24,6 +24,11 @@ def main():
     ap.add_argument("--top", type=int, default=25)
     ap.add_argument("--last", type=int, default=0, help="only the last N dispatches (steady-state steps after MIOpen's find)")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
+    ap.add_argument("--json", default=None, help="write profiles/mfma.json (stamped with the sources and the workload; bench.py "
+                                                 "quotes it only while both still match)")
+    ap.add_argument("--steps", type=float, default=1.0, help="training steps covered by the selected dispatches")
+    ap.add_argument("--workload", default="cfg_kitti_tripleD.py B=12 192x640")
+    ap.add_argument("--source", default="")
     a = ap.parse_args()
     files = glob.glob(os.path.join(a.root, "**", "*counter_collection.csv"), recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -65,6 +70,29 @@ def main():
     print("MfmaUtil over ALL kernels of the step (time-weighted):     %.1f %%" % (100 * sum(r[1] * r[0] for r in rows) / tot_act))
     raw = {k: sum(c.get(k, 0.0) for c in acc.values()) for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CU_CYCLES", "__ns")}
     print("raw sums:", raw)
+    own = [r for r in rows if "conv1x1_mfma_kernel" in r[4]]
+    if own:
+        oa = sum(r[0] for r in own)
+        print("MfmaUtil over the hand-written td::conv1x1_mfma_kernel launches (time-weighted): %.1f %% (%.2f %% of the dispatch-busy cycles)"
+              % (100 * sum(r[1] * r[0] for r in own) / oa, 100 * oa / tot_act))
+    if a.json:
+        import hashlib
+        import json
+        pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           "tripled-exploring-depth-estimation-with-self-supervised-representation-learning_amd")
+        files = ["csrc/td_conv1x1.hip", "csrc/td_bn.hip", "hostside/mono/model/networks.py", "ops.py"]
+        h = hashlib.sha256()
+        for rel in files:
+            with open(os.path.join(pkg, rel), "rb") as fh:
+                h.update(fh.read())
+        blob = {"source": a.source, "mfma_busy_cycles_per_step": raw["SQ_VALU_MFMA_BUSY_CYCLES"] / a.steps,
+                "mfma_util_conv_kernels": round(conv_mfma / max(conv_act, 1), 4),
+                "mfma_util_td_conv1x1": round(sum(r[1] * r[0] for r in own) / sum(r[0] for r in own), 4) if own else None,
+                "clock_ghz": a.clock_ghz, "simds": a.cus * 4,
+                "calibration": "8192^3 bf16 GEMM: counter 47.9 % vs wall-clock 44.2 % of 2.5 PFLOP/s (profiles/r02/pmc_mfma_gemm_calibration.txt)",
+                "_stamp": {"sources_sha16": h.hexdigest()[:16], "sources": files, "workload": a.workload}}
+        with open(a.json, "w") as fh:
+            json.dump(blob, fh, indent=1)
     print("%8s %9s %7s  kernel" % ("share", "MfmaUtil", "calls"))
     for act, util, _, n, name in rows[:a.top]:
         print("%7.2f%% %8.1f%% %7d  %s" % (100 * act / tot_act, 100 * util, n, name[:120]))

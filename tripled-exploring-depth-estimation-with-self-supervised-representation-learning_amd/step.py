@@ -190,6 +190,29 @@ def capture_step(step, stream=None, split=False, capture_error_mode="global", va
     return g
 
 
+def ranks_agree(ok, device):
+    """True on every rank iff ``ok`` is True on every rank (all_reduce(MIN)); a one-process job returns ``ok``.  Every rank
+    must call it the same number of times: it is how the ranks settle which step form they all run."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(ok)
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0)
+
+
+def replicas_agree(model, rel=1e-6):
+    """Data-parallel replicas must hold identical parameters after a synchronised update: compares a checksum (sum of all
+    parameter sums, in float64) over the ranks.  True on every rank iff the minimum and the maximum coincide."""
+    params = [p for p in model.parameters()]
+    chk = torch.stack([p.detach().double().sum() for p in params]).sum().reshape(1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return True
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(hi - lo) <= rel * max(1.0, abs(float(hi)))
+
+
 class RunnerIteration:
     """The training iteration of ``train.py`` as a HIP-graph replay, in the Runner's ``batch_processor`` slot.
 
@@ -258,11 +281,7 @@ class RunnerIteration:
         return ([] if self.syncbn else ["two-graph"]) + ["eager"]
 
     def _agree(self, ok):
-        if self._world() == 1:
-            return ok
-        flag = torch.tensor([1.0 if ok else 0.0], device=self.step.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item() > 0)
+        return ranks_agree(ok, self.step.device)
 
     def _capture(self):
         stream = self.side if single_stream_capture_ok() else None
