@@ -166,7 +166,7 @@ def roofline_of_hot_kernels(cfg, batch):
     argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
     coef = torch.empty(B, 9, H, W, device=dev)
     part = torch.empty(lib.td_photo_num_blocks(B, H, W), device=dev)
-    d_up = torch.empty(B, H, W, device=dev)
+    d_up = torch.empty(n_src, B, H, W, device=dev)      # one plane per source frame (td_photo_bwd)
     dpp = torch.empty(lib.td_photo_bwd_num_blocks(B, H, W), n_src * 12, device=dev)
     gs = torch.ones(1, device=dev)
     st = native.stream()

@@ -102,9 +102,10 @@ int td_photo_fwd(const float* tgt, const float* const* src, int n_src,
  * same lines).  The warp is recomputed in-kernel; argmin and coef come from the forward.
  *   gscale    device scalar: d(total)/d(loss_s) as handed over by autograd
  *   inv_count 1 / (B*H*W*n_scales)  (the mean and the /len(scales) of net.py:117)
- *   d_up      [B,H,W] (out, workspace): gradient w.r.t. the UPSAMPLED disparity
+ *   d_up      [n_src,B,H,W] (out, workspace): gradient w.r.t. the UPSAMPLED disparity, one plane per source frame
+ *             (the frames of a column strip are separate wave tasks; their sum is the gradient)
  *   dP_partial[td_photo_bwd_num_blocks, n_src*12] (out): per-block partial sums of dL/dP
- * Follow with td_upsample_adjoint (d_up -> d_disp) and td_reduce_dP.
+ * Follow with td_upsample_adjoint_planes (d_up planes -> d_disp) and td_reduce_dP.
  */
 int td_photo_bwd(const float* tgt, const float* const* src, int n_src,
                  const float* disp, const float* P, const float* invK,
@@ -119,6 +120,10 @@ int td_photo_bwd(const float* tgt, const float* const* src, int n_src,
  * accumulate != 0 adds into d_disp instead of overwriting it. Gather form, deterministic. */
 int td_upsample_adjoint(const float* d_up, int B, int H, int W, int hs, int ws,
                         float* d_disp, int accumulate, td_stream_t stream);
+/* The same adjoint of the SUM of n_planes gradient planes d_up [n_planes,B,H,W] (td_photo_bwd's per-frame planes), summed in
+ * plane order while gathering. */
+int td_upsample_adjoint_planes(const float* d_up, int n_planes, int B, int H, int W, int hs, int ws,
+                               float* d_disp, int accumulate, td_stream_t stream);
 
 /* dP[i,b,:,:] = sum over the blocks of sample b of dP_partial (deterministic tree). */
 int td_reduce_dP(const float* dP_partial, int n_src, int B, int H, int W,

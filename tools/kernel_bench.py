@@ -64,7 +64,7 @@ def main():
     argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
     coef = torch.empty(B, 9, H, W, device=dev)
     part = torch.empty(lib.td_photo_num_blocks(B, H, W), device=dev)
-    d_up = torch.empty(B, H, W, device=dev)
+    d_up = torch.empty(n_src, B, H, W, device=dev)      # one plane per source frame (td_photo_bwd)
     dpp = torch.empty(lib.td_photo_bwd_num_blocks(B, H, W), n_src * 12, device=dev)
     dP = torch.empty(n_src, B, 3, 4, device=dev)
     gs = torch.ones(1, device=dev)
@@ -128,7 +128,7 @@ def main():
                                           0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
 
         def adj():
-            native.check(lib.td_upsample_adjoint(native.ptr(d_up), B, H, W, hs, ws, native.ptr(d_disp), 0, st), "adj")
+            native.check(lib.td_upsample_adjoint_planes(native.ptr(d_up), n_src, B, H, W, hs, ws, native.ptr(d_disp), 0, st), "adj")
 
         def red():
             native.check(lib.td_reduce_dP(native.ptr(dpp), n_src, B, H, W, native.ptr(dP), st), "red")

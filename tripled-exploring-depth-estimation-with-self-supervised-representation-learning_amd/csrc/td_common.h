@@ -238,12 +238,12 @@ __device__ __forceinline__ float hsum3(float v) { return (lane_left(v) + v) + la
 // thirteen-row tasks one round of 15 (measured: 116 -> 92 us for the backward).  Pure function of the shape, so
 // the *_num_blocks entry points and the launches agree.
 constexpr int TD_WAVE_SLOTS = 256 * 4 * 2;
-static inline int pick_rows(int units, int H, int halo, int step, int lo, int hi) {
+static inline int pick_rows(int units, int H, int halo, int step, int lo, int hi, int slots = TD_WAVE_SLOTS) {
   int best = lo;
   long long best_cost = -1;
   for (int r = lo; r <= hi; r += step) {
     const long long tasks = (long long)units * ((H + r - 1) / r);
-    const long long rounds = (tasks + TD_WAVE_SLOTS - 1) / TD_WAVE_SLOTS;
+    const long long rounds = (tasks + slots - 1) / slots;
     const long long cost = rounds * (r + halo);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }   // ties keep the smaller tile
   }

@@ -2,14 +2,16 @@
 // coefficients per channel of the warped frame its arg-min selected
 // (d SSIM_p / d x_q = (alpha_p + beta_p x_q + gamma_p y_q) / 9 for every member q of p's window), so the
 // adjoint of the 3x3 windows is a box filter over that field and nothing is scattered.
-// A wave owns a strip of 62 columns and marches down the rows, once per source frame; per row it
+// A wave owns a strip of 62 columns of ONE source frame and marches down the rows (the frames of a strip are separate wave
+// tasks, adjacent in the task order so that they share the coefficient / target / arg-min rows in one XCD's L2: a
+// one-frame body needs 164 registers instead of 256, i.e. three waves per SIMD instead of two); per row it
 //   1. re-warps the source (two-deep load pipeline as in the forward) and forms d x_c / d(u, v),
 //   2. box-filters the coefficient field (horizontal: DPP lane shifts, vertical: two-row register
 //      ring; reflection padding = integer multiplicities) -> d loss / d warped pixel one row back,
 //      adds the robust-L1 adjoint,
 //   3. chains through the bilinear sampler, the projection and the depth.
-// No LDS, no barriers, no atomics: d_up is written once per pixel per frame (first frame stores,
-// later frames add), dL/dP is accumulated in registers and written once per wave.
+// No LDS, no barriers, no atomics: every frame task writes its own d_up plane once per pixel (td_upsample_adjoint_planes sums
+// the planes while it gathers), dL/dP is accumulated in registers and written once per wave.
 // The library is built with -ffp-contract=off for the forward's sake (SSIM variances).  The adjoint has no such
 // cancellation, so this translation unit lets the compiler fuse multiply-adds (-4 % time; gradients move by ~1 ulp).
 #pragma clang fp contract(fast)
@@ -41,13 +43,14 @@ struct PhotoBwdArgs {
 };
 
 template <int NS>
-// second bound: two waves per SIMD (<= 256 registers, no spills); without it the two-row body is scheduled into 278
-__global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
+// second bound: three waves per SIMD (<= 168 registers; the one-frame body takes 164 without spills)
+__global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int bid = (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3);
-  const int task = bid * BS_WAVES + wave;
-  if (task >= a.ntasks) return;
+  const int ftask = bid * BS_WAVES + wave;           // (strip task, frame), frame fastest
+  if (ftask >= a.ntasks * NS) return;
+  const int f = ftask % NS, task = ftask / NS;
   const int strip = task % a.nstrips;
   const int chunk = (task / a.nstrips) % a.nchunks;
   const int b = task / (a.nstrips * a.nchunks);
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const Photo
   const float* tgtb = a.tgt + (size_t)b * 3 * plane;
   const float* cfb = a.coef + (size_t)b * 9 * plane;
   const uint8_t* amb = a.argmin + (size_t)b * plane;
-  float* dupb = a.d_up + (size_t)b * plane;
+  float* dupb = a.d_up + ((size_t)f * a.B + b) * plane;      // this frame's plane of d_up [NS,B,H,W]
   const float* dispb = a.disp + (size_t)b * a.hs * a.ws;
   float ik[9];
 #pragma unroll
@@ -78,9 +81,11 @@ __global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const Photo
   const float sx_scale = (float)W / (float)(W - 1), sy_scale = (float)H / (float)(H - 1);   // d ix / d u, d iy / d v
   const int NK = a.rows + 2;
 
-#pragma unroll 1
-  for (int f = 0; f < NS; ++f) {
-    const float* srcb = a.src[f] + (size_t)b * 3 * plane;
+  {
+    const float* srcp = a.src[0];                    // (a select chain: dynamic indexing of the by-value argument struct would go to scratch)
+#pragma unroll
+    for (int i = 1; i < NS; ++i) srcp = (f == i) ? a.src[i] : srcp;
+    const float* srcb = srcp + (size_t)b * 3 * plane;
     float P[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) P[e] = a.P[(f * a.B + b) * 12 + e];
@@ -233,8 +238,7 @@ __global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const Photo
         const float dZ = dc0 * P[2] + dc1 * P[6] + dc2 * P[10];
         const float dD = dX * r0 + dY * r1 + dZ * r2;
         const float contrib = dD * (-a.disp_range * dq * dq);
-        float* dst = dupb + (unsigned)(q * W + x);
-        if (f == 0) *dst = contrib; else *dst += contrib;
+        dupb[(unsigned)(q * W + x)] = contrib;
       }
     };
     int k = 0;
@@ -252,9 +256,12 @@ __global__ __launch_bounds__(BS_WAVES * 64, 2) void photo_bwd_kernel(const Photo
   }
 }
 
+// strip tasks (each is run once per source frame).  The row tiling is a function of (B, H, W) only, so that
+// td_photo_bwd_num_blocks / td_reduce_dP agree with the launch for every frame count: it is sized for two frame tasks per
+// strip (the monocular configurations) at three resident waves per SIMD.
 static int bwd_tasks(int B, int H, int W, int* nstrips, int* nchunks, int* rows) {
   *nstrips = (W + BS_COLS - 1) / BS_COLS;
-  *rows = pick_rows(B * (*nstrips), H, 2, 1, 8, 64);
+  *rows = pick_rows(B * (*nstrips) * 2, H, 2, 1, 8, 64, 256 * 4 * 3);
   *nchunks = (H + *rows - 1) / *rows;
   return B * (*nstrips) * (*nchunks);
 }
@@ -276,7 +283,7 @@ static int run_bwd(const float* tgt, const float* const* src, const float* disp,
   a.min_disp = (float)lo;
   a.disp_range = (float)(hi - lo);
   a.ntasks = bwd_tasks(B, H, W, &a.nstrips, &a.nchunks, &a.rows);
-  const int blocks = (a.ntasks + BS_WAVES - 1) / BS_WAVES;
+  const int blocks = (a.ntasks * NS + BS_WAVES - 1) / BS_WAVES;
   a.blocks_per_xcd = (blocks + 7) / 8;
   hipLaunchKernelGGL((photo_bwd_kernel<NS>), dim3(a.blocks_per_xcd * 8), dim3(BS_WAVES * 64), 0, st, a);
   return record_launch_error(hipGetLastError(), "td_photo_bwd");
@@ -301,10 +308,86 @@ __global__ __launch_bounds__(64) void reduce_dP_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// Adjoint of the bilinear up-sampling, gather form: G lanes cooperate on one low-res pixel.
-template <int G>
+// Adjoint of the bilinear up-sampling, separable gather form.  A block owns a tile of TJ x TI low-res pixels:
+//   1. row pass: t[y][i] = sum_x wx(x, i) * (sum over the planes of d_up[y][x]) for the full-res rows y the tile's rows can
+//      receive from, kept in LDS (at most (TJ + 2) * H/hs + 4 rows of TI floats);
+//   2. column pass: d_disp[j][i] = sum_y wy(y, j) * t[y][i].
+// Every full-res value is read once per tile row-range (1.25-1.5x in all) instead of once per low-res pixel it can reach
+// (the earlier one-launch gather read each value ~9 times at factor 2 and took 35-44 us of the 96x320 level's 60 us
+// backward).  Weights are ATen's (up_index), evaluated per tap; fixed summation order: deterministic.
+template <int TJ, int TI>
 __global__ __launch_bounds__(TD_THREADS) void upsample_adjoint_kernel(
-    const float* __restrict__ d_up, int B, int H, int W, int hs, int ws,
+    const float* __restrict__ d_up, int n_planes, int B, int H, int W, int hs, int ws, int tiles_i, int tiles_j,
+    float* __restrict__ d_disp, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float t_rows[];
+  const int ti = blockIdx.x % tiles_i, tj = (blockIdx.x / tiles_i) % tiles_j, b = blockIdx.x / (tiles_i * tiles_j);
+  const int i0 = ti * TI, j0 = tj * TJ;
+  const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
+  const float fy = (float)H / (float)hs, fx = (float)W / (float)ws;
+  int ylo = (int)floorf(((float)j0 - 0.5f) * fy - 0.5f) - 1;
+  int yhi = (int)ceilf(((float)(j0 + TJ - 1) + 1.5f) * fy - 0.5f) + 1;
+  ylo = ylo < 0 ? 0 : ylo;
+  yhi = yhi > H - 1 ? H - 1 : yhi;
+  const int nrows = yhi - ylo + 1;
+  const size_t plane = (size_t)B * H * W;
+  const float* src = d_up + (size_t)b * H * W;
+  for (int item = threadIdx.x; item < nrows * TI; item += TD_THREADS) {
+    const int yy = ylo + item / TI, ii = i0 + item % TI;
+    float acc = 0.f;
+    if (ii < ws) {
+      int xlo = (int)floorf(((float)ii - 0.5f) * fx - 0.5f) - 1;
+      int xhi = (int)ceilf(((float)ii + 1.5f) * fx - 0.5f) + 1;
+      xlo = xlo < 0 ? 0 : xlo;
+      xhi = xhi > W - 1 ? W - 1 : xhi;
+      const float* row = src + (size_t)yy * W;
+      for (int xx = xlo; xx <= xhi; ++xx) {
+        const UpIdx vx = up_index(xx, rx, ws);
+        const float wx = (vx.i0 == ii ? vx.l0 : 0.f) + (vx.i1 == ii ? vx.l1 : 0.f);
+        if (wx != 0.f) {
+          float v = row[xx];
+          for (int p = 1; p < n_planes; ++p) v += row[(size_t)p * plane + xx];     // per-frame planes, in order
+          acc += wx * v;
+        }
+      }
+    }
+    t_rows[item] = acc;
+  }
+  __syncthreads();
+  for (int out = threadIdx.x; out < TJ * TI; out += TD_THREADS) {
+    const int jj = j0 + out / TI, ii = i0 + out % TI;
+    if (jj >= hs || ii >= ws) continue;
+    int y0 = (int)floorf(((float)jj - 0.5f) * fy - 0.5f) - 1;
+    int y1 = (int)ceilf(((float)jj + 1.5f) * fy - 0.5f) + 1;
+    y0 = y0 < ylo ? ylo : y0;
+    y1 = y1 > yhi ? yhi : y1;
+    float acc = 0.f;
+    for (int yy = y0; yy <= y1; ++yy) {
+      const UpIdx vy = up_index(yy, ry, hs);
+      const float wy = (vy.i0 == jj ? vy.l0 : 0.f) + (vy.i1 == jj ? vy.l1 : 0.f);
+      if (wy != 0.f) acc += wy * t_rows[(yy - ylo) * TI + (ii - i0)];
+    }
+    float* dst = d_disp + ((size_t)b * hs + jj) * ws + ii;
+    if (accumulate) *dst += acc; else *dst = acc;
+  }
+}
+
+template <int TJ, int TI>
+static int launch_upsample_adjoint(const float* d_up, int n_planes, int B, int H, int W, int hs, int ws, float* d_disp, int accumulate,
+                                   hipStream_t st) {
+  const int tiles_i = (ws + TI - 1) / TI, tiles_j = (hs + TJ - 1) / TJ;
+  const int max_rows = (int)((TJ + 2) * ((double)H / hs)) + 6;
+  const size_t lds = (size_t)max_rows * TI * sizeof(float);
+  if (lds > 64 * 1024) return TD_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((upsample_adjoint_kernel<TJ, TI>), dim3(tiles_i * tiles_j * B), dim3(TD_THREADS), lds, st, d_up, n_planes, B, H, W, hs,
+                     ws, tiles_i, tiles_j, d_disp, accumulate);
+  return record_launch_error(hipGetLastError(), "td_upsample_adjoint");
+}
+
+// Large factors (> 10: the 12x40 level of a 192x640 image): G lanes cooperate on one low-res pixel's whole window; there the
+// tiled form above has too few tiles to cover the chip (30 us against 21 us at factor 16).
+template <int G>
+__global__ __launch_bounds__(TD_THREADS) void upsample_adjoint_gather_kernel(
+    const float* __restrict__ d_up, int n_planes, int B, int H, int W, int hs, int ws,
     float* __restrict__ d_disp, int accumulate) {
   const int gid = (blockIdx.x * TD_THREADS + threadIdx.x) / G;
   const int sub = threadIdx.x % G;
@@ -330,7 +413,11 @@ __global__ __launch_bounds__(TD_THREADS) void upsample_adjoint_kernel(
     const float wy = (vy.i0 == j ? vy.l0 : 0.f) + (vy.i1 == j ? vy.l1 : 0.f);
     const float wx = (vx.i0 == i ? vx.l0 : 0.f) + (vx.i1 == i ? vx.l1 : 0.f);
     const float w = wy * wx;
-    if (w != 0.f) acc += w * src[(size_t)yy * W + xx];
+    if (w != 0.f) {
+      float v = src[(size_t)yy * W + xx];
+      for (int p = 1; p < n_planes; ++p) v += src[(size_t)p * B * H * W + (size_t)yy * W + xx];
+      acc += w * v;
+    }
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, G);
@@ -386,21 +473,26 @@ extern "C" int td_reduce_partials(const float* partial, int n_src, int B, int bl
   return td::record_launch_error(hipGetLastError(), "td_reduce_partials");
 }
 
+extern "C" int td_upsample_adjoint_planes(const float* d_up, int n_planes, int B, int H, int W, int hs, int ws, float* d_disp,
+                                          int accumulate, td_stream_t stream);
+
 extern "C" int td_upsample_adjoint(const float* d_up, int B, int H, int W, int hs, int ws,
                                    float* d_disp, int accumulate, td_stream_t stream) {
-  if (!d_up || !d_disp || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W) return TD_ERR_BAD_ARG;
+  return td_upsample_adjoint_planes(d_up, 1, B, H, W, hs, ws, d_disp, accumulate, stream);
+}
+
+extern "C" int td_upsample_adjoint_planes(const float* d_up, int n_planes, int B, int H, int W, int hs, int ws, float* d_disp,
+                                          int accumulate, td_stream_t stream) {
+  if (!d_up || !d_disp || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W || n_planes < 1 || n_planes > TD_MAX_SRC) return TD_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int total = B * hs * ws;
-  const float f = fmaxf((float)H / (float)hs, (float)W / (float)ws);
-  if (f <= 2.5f) {
-    const int blocks = (total * 4 + TD_THREADS - 1) / TD_THREADS;
-    hipLaunchKernelGGL(td::upsample_adjoint_kernel<4>, dim3(blocks), dim3(TD_THREADS), 0, st, d_up, B, H, W, hs, ws, d_disp, accumulate);
-  } else if (f <= 5.f) {
-    const int blocks = (total * 16 + TD_THREADS - 1) / TD_THREADS;
-    hipLaunchKernelGGL(td::upsample_adjoint_kernel<16>, dim3(blocks), dim3(TD_THREADS), 0, st, d_up, B, H, W, hs, ws, d_disp, accumulate);
-  } else {
-    const int blocks = (total * 64 + TD_THREADS - 1) / TD_THREADS;
-    hipLaunchKernelGGL(td::upsample_adjoint_kernel<64>, dim3(blocks), dim3(TD_THREADS), 0, st, d_up, B, H, W, hs, ws, d_disp, accumulate);
+  const float factor = fmaxf((float)H / (float)hs, (float)W / (float)ws);
+  if (factor > 10.f) {
+    const int blocks = (B * hs * ws * 64 + TD_THREADS - 1) / TD_THREADS;
+    hipLaunchKernelGGL(td::upsample_adjoint_gather_kernel<64>, dim3(blocks), dim3(TD_THREADS), 0, st, d_up, n_planes, B, H, W, hs, ws, d_disp,
+                       accumulate);
+    return td::record_launch_error(hipGetLastError(), "td_upsample_adjoint");
   }
-  return td::record_launch_error(hipGetLastError(), "td_upsample_adjoint");
+  // tile of low-res pixels per block: large maps take 8 x 32, small ones 4 x 8 so that the grid still covers the chip
+  if ((long long)B * hs * ws >= 64 * 1024) return td::launch_upsample_adjoint<8, 32>(d_up, n_planes, B, H, W, hs, ws, d_disp, accumulate, st);
+  return td::launch_upsample_adjoint<4, 8>(d_up, n_planes, B, H, W, hs, ws, d_disp, accumulate, st);
 }

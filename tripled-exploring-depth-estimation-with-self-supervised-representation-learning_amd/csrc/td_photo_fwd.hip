@@ -9,6 +9,15 @@
 // taps of row r+2 are in flight, so a wave keeps ~30 loads outstanding without relying on
 // occupancy.  Blocks are remapped so that consecutive tasks (neighbouring strips / row chunks
 // that share halo lines) land on the same XCD and hit its L2.
+//
+// SPLIT form (built, parity-tested, NOT dispatched: kSplitFrames below): the frames of a strip as separate waves of one
+// block.  A one-frame wave needs 148 registers instead of 215 (three waves per SIMD instead of two); each wave reduces its
+// own frame to the per-pixel loss, the losses meet in a 2 KB LDS exchange (one barrier per row, slots alternate by row
+// parity), every wave forms the same arg-min, wave 0 writes it, and each wave writes the SSIM-adjoint coefficients where ITS
+// frame won (wave 0 also the zeros where an identity term won).  Measured at B=12 192x640 scale 0: 68.8 us against 62.1 us
+// for the frames-in-one-wave form -- the target row's window sums, the auto-mask loads and the selection are done once per
+// frame wave instead of once per strip (+25 % horizontal sums) and the barrier couples the pair; the extra resident wave
+// does not pay for that.  (The backward, whose frames share no arithmetic, gained 11 % from the same split.)
 #include <type_traits>
 
 #include "td_common.h"
@@ -46,12 +55,12 @@ struct UpRow {
 };
 
 // Everything one pipeline row needs, requested one iteration ahead of its use.
-template <int NS>
+template <int NF, int NS>     // NF: frames this wave warps (1 in the split form), NS: all source frames (auto-mask terms)
 struct RowLoads {
-  Tap taps[NS];
-  TapVals tv[NS][3];
+  Tap taps[NF];
+  TapVals tv[NF][3];
   float yv[3];
-  float xv[NS][3];     // identity mode: raw source pixels
+  float xv[NF][3];     // identity mode: raw source pixels
   float idv[NS];       // auto-mask term of the output row this pipeline row completes
   float nz[NS];
 };
@@ -63,16 +72,24 @@ struct DispTaps {
 
 // MODE: 0 = identity-term kernel, 1 = warped terms only, 2 = + auto-mask, 3 = + auto-mask noise.
 // KEEP: also write the warped sources.
-template <int NS, int MODE, bool KEEP, bool COEF>
-__global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwdArgs<NS> a) {
+template <int NS, int MODE, bool KEEP, bool COEF, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, SPLIT ? 3 : 1) void photo_fwd_kernel(const PhotoFwdArgs<NS> a) {
   constexpr bool IDENT = MODE == 0;
+  static_assert(!SPLIT || (NS >= 2 && MODE >= 1), "the split form is for the warped terms of >= 2 frames");
+  constexpr int NF = SPLIT ? 1 : NS;                 // frames this wave reduces
+  constexpr int SPB = SPLIT ? FS_WAVES / NS : FS_WAVES;   // strip tasks per block
+  __shared__ float xch[SPLIT ? 2 * SPB * NS * 64 : 1];    // [row parity][strip of the block][frame][lane]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int fw = SPLIT ? wave % NS : 0;              // this wave's frame (split form)
+  const int slot = SPLIT ? wave / NS : wave;         // strip task of the block
   // XCD-aware remap: hardware deals consecutive blocks round-robin over the 8 XCDs; give every
   // XCD a contiguous range of tasks instead (speed only, any placement is correct)
   const int bid = (int)(blockIdx.x & 7) * a.blocks_per_xcd + (int)(blockIdx.x >> 3);
-  const int task = bid * FS_WAVES + wave;
-  if (task >= a.ntasks) return;
+  int task = bid * SPB + slot;
+  bool live = task < a.ntasks;
+  if (!SPLIT && !live) return;
+  task = live ? task : a.ntasks - 1;                 // split form: every wave keeps marching (barriers); stores are masked
   const int strip = task % a.nstrips;
   const int chunk = (task / a.nstrips) % a.nchunks;
   const int b = task / (a.nstrips * a.nchunks);
@@ -82,16 +99,23 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   const int x = strip * FS_COLS - 1 + lane;          // padded-domain column of this lane
   const int qx = reflect1(x, W);
   const int y0 = chunk * a.rows;
-  const bool col_out = lane >= 1 && lane <= FS_COLS && x < W;
+  const bool col_out = live && lane >= 1 && lane <= FS_COLS && x < W;
   const int xo = x < W ? (x < 0 ? 0 : x) : W - 1;    // clamped column for prefetching per-pixel inputs
 
   const float* tgtb = a.tgt + (size_t)b * 3 * plane;
-  const float* srcb[NS];
+  const float* srcb[NF];
 #pragma unroll
-  for (int f = 0; f < NS; ++f) srcb[f] = a.src[f] + (size_t)b * 3 * plane;
+  for (int f = 0; f < NF; ++f) {
+    const float* p = a.src[SPLIT ? 0 : f];
+    if (SPLIT) {
+#pragma unroll
+      for (int i = 1; i < NS; ++i) p = (fw == i) ? a.src[i] : p;
+    }
+    srcb[f] = p + (size_t)b * 3 * plane;
+  }
 
   // ---- per-wave constants: camera, per-lane horizontal up-sampling taps, x part of the rays ----
-  float ik[9], P[NS][12];
+  float ik[9], P[NF][12];
   UpIdx ux;
   ux.i0 = ux.i1 = 0; ux.l0 = ux.l1 = 0.f;
   float rx0 = 0.f, rx1 = 0.f, rx2 = 0.f;
@@ -101,9 +125,9 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
 #pragma unroll
     for (int i = 0; i < 9; ++i) ik[i] = a.invK[b * 16 + (i / 3) * 4 + (i % 3)];
 #pragma unroll
-    for (int f = 0; f < NS; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int e = 0; e < 12; ++e) P[f][e] = a.P[(f * a.B + b) * 12 + e];
+      for (int e = 0; e < 12; ++e) P[f][e] = a.P[((SPLIT ? fw : f) * a.B + b) * 12 + e];
     ux = up_index(qx, (float)a.ws / (float)W, a.ws);
     ratio_y = (float)a.hs / (float)H;
     const float fx = (float)qx;
@@ -118,14 +142,14 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
     d.v[0] = ld_at(dispb, (unsigned)(d.ur.o0 + ux.i0) * 4u); d.v[1] = ld_at(dispb, (unsigned)(d.ur.o0 + ux.i1) * 4u);
     d.v[2] = ld_at(dispb, (unsigned)(d.ur.o1 + ux.i0) * 4u); d.v[3] = ld_at(dispb, (unsigned)(d.ur.o1 + ux.i1) * 4u);
   };
-  auto stage_b = [&](int k, const DispTaps& d, RowLoads<NS>& L) {   // taps + gathers of pipeline row k
+  auto stage_b = [&](int k, const DispTaps& d, RowLoads<NF, NS>& L) {   // taps + gathers of pipeline row k
     const int qy = reflect1(y0 - 1 + k, H);
     const unsigned off = (unsigned)(qy * W + qx);
 #pragma unroll
     for (int c = 0; c < 3; ++c) L.yv[c] = ld_at(tgtb + (size_t)c * plane, off * 4u);
     if (IDENT) {
 #pragma unroll
-      for (int f = 0; f < NS; ++f)
+      for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int c = 0; c < 3; ++c) L.xv[f][c] = ld_at(srcb[f] + (size_t)c * plane, off * 4u);
     } else {
@@ -136,12 +160,12 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
       const float r1 = rx1 + ik[4] * fy + ik[5];
       const float r2 = rx2 + ik[7] * fy + ik[8];
 #pragma unroll
-      for (int f = 0; f < NS; ++f) {
+      for (int f = 0; f < NF; ++f) {
         float pt[3], cz[3];
         L.taps[f] = project_ray(r0, r1, r2, P[f], depth, W, H, pt, cz);
       }
 #pragma unroll
-      for (int f = 0; f < NS; ++f)
+      for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int c = 0; c < 3; ++c) L.tv[f][c] = load_taps(srcb[f] + c * plane, W, L.taps[f]);
       if (MODE >= 2) {        // per-pixel inputs of the output row that pipeline row k completes
@@ -159,13 +183,13 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   };
 
   // two-row ring of horizontal sums + centre values of the previous row
-  float p_hy[2][3], p_hyy[2][3], p_hx[2][NS][3], p_hxx[2][NS][3], p_hxy[2][NS][3];
-  float c_y[3], c_x[NS][3];
+  float p_hy[2][3], p_hyy[2][3], p_hx[2][NF][3], p_hxx[2][NF][3], p_hxy[2][NF][3];
+  float c_y[3], c_x[NF][3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     p_hy[0][c] = p_hy[1][c] = p_hyy[0][c] = p_hyy[1][c] = c_y[c] = 0.f;
 #pragma unroll
-    for (int f = 0; f < NS; ++f)
+    for (int f = 0; f < NF; ++f)
       p_hx[0][f][c] = p_hx[1][f][c] = p_hxx[0][f][c] = p_hxx[1][f][c] = p_hxy[0][f][c] = p_hxy[1][f][c] = c_x[f][c] = 0.f;
   }
   float acc = 0.f;
@@ -174,33 +198,34 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   // shifted: ring slot RO = k & 1 holds the older row and receives this row's sums (the loop is unrolled by two, so
   // RO is a compile-time constant).  In the backward this form removed 40 register moves per row; here the
   // compiler had already coalesced the shifts of the unrolled loop (same instruction count either way)
-  auto consume = [&](auto ro_tag, int k, const RowLoads<NS>& cur, bool emit_allowed) {
+  auto consume = [&](auto ro_tag, int k, const RowLoads<NF, NS>& cur, bool emit_allowed) {
     constexpr int RO = decltype(ro_tag)::value, RN = 1 - RO;
-    float y[3], xw[NS][3];
+    float y[3], xw[NF][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) y[c] = cur.yv[c];
 #pragma unroll
-    for (int f = 0; f < NS; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int c = 0; c < 3; ++c) xw[f][c] = IDENT ? cur.xv[f][c] : blend_taps(cur.tv[f][c], cur.taps[f]);
     const int r = y0 - 1 + k;
     if (KEEP && !IDENT && k >= 1 && k <= a.rows && r < H && col_out) {
 #pragma unroll
-      for (int f = 0; f < NS; ++f)
+      for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.warped[(((size_t)f * a.B + b) * 3 + c) * plane + (unsigned)(r * W + x)] = xw[f][c];
+        for (int c = 0; c < 3; ++c)
+          a.warped[(((size_t)(SPLIT ? fw : f) * a.B + b) * 3 + c) * plane + (unsigned)(r * W + x)] = xw[f][c];
     }
-    float ss[NS], l1[NS];
-    float cfs[COEF ? NS : 1][9];                     // (alpha, beta, gamma) per channel of every warped frame
+    float ss[NF], l1[NF];
+    float cfs[COEF ? NF : 1][9];                     // (alpha, beta, gamma) per channel of every warped frame of this wave
 #pragma unroll
-    for (int f = 0; f < NS; ++f) { ss[f] = 0.f; l1[f] = 0.f; }
+    for (int f = 0; f < NF; ++f) { ss[f] = 0.f; l1[f] = 0.f; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float hy = hsum3(y[c]);
       const float hyy = hsum3(y[c] * y[c]);
-      float hx[NS], hxx[NS], hxy[NS];
+      float hx[NF], hxx[NF], hxy[NF];
 #pragma unroll
-      for (int f = 0; f < NS; ++f) {
+      for (int f = 0; f < NF; ++f) {
         hx[f] = hsum3(xw[f][c]);
         hxx[f] = hsum3(xw[f][c] * xw[f][c]);
         hxy[f] = hsum3(xw[f][c] * y[c]);
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
         const float sy = p_hy[RO][c] + p_hy[RN][c] + hy;
         const float syy = p_hyy[RO][c] + p_hyy[RN][c] + hyy;
 #pragma unroll
-        for (int f = 0; f < NS; ++f) {
+        for (int f = 0; f < NF; ++f) {
           const float sx = p_hx[RO][f][c] + p_hx[RN][f][c] + hx[f];
           const float sxx = p_hxx[RO][f][c] + p_hxx[RN][f][c] + hxx[f];
           const float sxy = p_hxy[RO][f][c] + p_hxy[RN][f][c] + hxy[f];
@@ -228,7 +253,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
       p_hyy[RO][c] = hyy;
       c_y[c] = y[c];
 #pragma unroll
-      for (int f = 0; f < NS; ++f) {
+      for (int f = 0; f < NF; ++f) {
         p_hx[RO][f][c] = hx[f];
         p_hxx[RO][f][c] = hxx[f];
         p_hxy[RO][f][c] = hxy[f];
@@ -236,11 +261,20 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
       }
     }
     const int orow = r - 1;
+    float loss[NS];                                  // the per-pixel loss of EVERY warped frame
+#pragma unroll
+    for (int f = 0; f < NF; ++f) loss[SPLIT ? 0 : f] = 0.85f * (ss[f] * (1.f / 3.f)) + 0.15f * (l1[f] * (1.f / 3.f));
+    if (SPLIT && emit_allowed) {
+      // the frames of this strip meet here: one slot set per row parity, one barrier per row (every wave of the block runs
+      // the same row sequence, so the barrier is block-uniform; a slot is rewritten two rows later, behind the next barrier)
+      float* xs = xch + ((RO * SPB + slot) * NS) * 64;
+      xs[fw * 64 + lane] = loss[0];
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < NS; ++f) loss[f] = xs[f * 64 + lane];
+    }
     if (emit_allowed && orow < H && col_out) {
       const unsigned pix = (unsigned)(orow * W + x);
-      float loss[NS];
-#pragma unroll
-      for (int f = 0; f < NS; ++f) loss[f] = 0.85f * (ss[f] * (1.f / 3.f)) + 0.15f * (l1[f] * (1.f / 3.f));
       if (IDENT) {
 #pragma unroll
         for (int f = 0; f < NS; ++f) a.idloss_out[(size_t)(b * NS + f) * plane + pix] = loss[f];
@@ -259,16 +293,27 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
 #pragma unroll
         for (int f = 0; f < NS; ++f)
           if (!have || loss[f] < best) { best = loss[f]; idx = base + f; have = true; }
-        a.argmin[(size_t)b * plane + pix] = (uint8_t)idx;
-        if (a.min_map != nullptr) a.min_map[(size_t)b * plane + pix] = best;
-        acc += best;
+        if (!SPLIT || fw == 0) {
+          a.argmin[(size_t)b * plane + pix] = (uint8_t)idx;
+          if (a.min_map != nullptr) a.min_map[(size_t)b * plane + pix] = best;
+          acc += best;
+        }
         if (COEF) {
+          if (SPLIT) {
+            // one writer per pixel: the wave whose frame won; wave 0 writes the zeros of an identity win
+            const bool won = idx == base + fw;
+            if (won || (fw == 0 && idx < base)) {
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            float v = 0.f;
+              for (int i = 0; i < 9; ++i) a.coef[((size_t)b * 9 + i) * plane + pix] = won ? cfs[0][i] : 0.f;
+            }
+          } else {
 #pragma unroll
-            for (int f = 0; f < NS; ++f) v = (idx == base + f) ? cfs[COEF ? f : 0][i] : v;
-            a.coef[((size_t)b * 9 + i) * plane + pix] = v;
+            for (int i = 0; i < 9; ++i) {
+              float v = 0.f;
+#pragma unroll
+              for (int f = 0; f < NF; ++f) v = (idx == base + f) ? cfs[COEF ? f : 0][i] : v;
+              a.coef[((size_t)b * 9 + i) * plane + pix] = v;
+            }
           }
         }
       }
@@ -277,7 +322,7 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
 
   // ---- two-deep software pipeline over NK = rows + 2 rows (even, >= 6: the loop is unrolled by two), ping-pong register sets ----
   const int NK = a.rows + 2;
-  RowLoads<NS> LA, LB;
+  RowLoads<NF, NS> LA, LB;
   DispTaps DA, DB;
   if (!IDENT) {
     stage_a(0, DA);
@@ -306,25 +351,33 @@ __global__ __launch_bounds__(FS_WAVES * 64) void photo_fwd_kernel(const PhotoFwd
   consume(even, NK - 2, LA, true);
   consume(odd, NK - 1, LB, true);
 
-  if (!IDENT) {
+  if (!IDENT && (!SPLIT || fw == 0)) {
     const float tot = wave_sum(acc);
-    if (lane == 0) a.partial[task] = tot;
+    if (lane == 0 && live) a.partial[task] = tot;
   }
 }
 
-static int fwd_tasks(int B, int H, int W, int* nstrips, int* nchunks, int* rows) {
+// Strip tasks.  The tiling is a function of (B, H, W) only (td_photo_num_blocks sizes `partial` without knowing the frame
+// count); with kSplitFrames the warped-term kernels would be tiled for two frame waves per strip at three waves per SIMD.
+constexpr bool kSplitFrames = false;
+
+static int fwd_tasks(int B, int H, int W, int* nstrips, int* nchunks, int* rows, bool ident = false) {
   *nstrips = (W + FS_COLS - 1) / FS_COLS;
-  *rows = pick_rows(B * (*nstrips), H, 2, 2, 8, 64);      // even
+  *rows = (ident || !kSplitFrames) ? pick_rows(B * (*nstrips), H, 2, 2, 8, 64)
+                                   : pick_rows(B * (*nstrips) * 2, H, 2, 2, 8, 64, 256 * 4 * 3);   // even
   *nchunks = (H + *rows - 1) / *rows;
   return B * (*nstrips) * (*nchunks);
 }
 
 template <int NS, int MODE, bool KEEP, bool COEF>
 static int launch_fwd(PhotoFwdArgs<NS>& a, hipStream_t st) {
-  a.ntasks = fwd_tasks(a.B, a.H, a.W, &a.nstrips, &a.nchunks, &a.rows);
-  const int blocks = (a.ntasks + FS_WAVES - 1) / FS_WAVES;
+  a.ntasks = fwd_tasks(a.B, a.H, a.W, &a.nstrips, &a.nchunks, &a.rows, MODE == 0);
+  constexpr bool SPLIT = kSplitFrames && NS >= 2 && MODE >= 1;
+  constexpr int SPB = SPLIT ? FS_WAVES / NS : FS_WAVES;          // strip tasks per block
+  const int blocks = (a.ntasks + SPB - 1) / SPB;
   a.blocks_per_xcd = (blocks + 7) / 8;
-  hipLaunchKernelGGL((photo_fwd_kernel<NS, MODE, KEEP, COEF>), dim3(a.blocks_per_xcd * 8), dim3(FS_WAVES * 64), 0, st, a);
+  hipLaunchKernelGGL((photo_fwd_kernel<NS, MODE, KEEP, COEF, SPLIT>), dim3(a.blocks_per_xcd * 8),
+                     dim3(SPLIT ? SPB * NS * 64 : FS_WAVES * 64), 0, st, a);
   return record_launch_error(hipGetLastError(), MODE == 0 ? "td_photo_identity" : "td_photo_fwd");
 }
 

@@ -86,7 +86,7 @@ class _PhotometricScaleLoss(torch.autograd.Function):
         hs, ws = disp.shape[2], disp.shape[3]
         dev = tgt.device
         g = _f32c(g_loss.reshape(1))
-        d_up = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+        d_up = torch.empty(n_src, B, H, W, device=dev, dtype=torch.float32)      # one plane per source frame
         nblk = lib.td_photo_bwd_num_blocks(B, H, W)
         dP_part = torch.empty(nblk, n_src * 12, device=dev, dtype=torch.float32)
         st = native.stream()
@@ -96,8 +96,8 @@ class _PhotometricScaleLoss(torch.autograd.Function):
                                       float(max_depth), native.ptr(d_up), native.ptr(dP_part), st),
                      "td_photo_bwd")
         d_disp = torch.empty_like(disp)
-        native.check(lib.td_upsample_adjoint(native.ptr(d_up), B, H, W, hs, ws, native.ptr(d_disp), 0, st),
-                     "td_upsample_adjoint")
+        native.check(lib.td_upsample_adjoint_planes(native.ptr(d_up), n_src, B, H, W, hs, ws, native.ptr(d_disp), 0, st),
+                     "td_upsample_adjoint_planes")
         dP = torch.empty_like(P)
         native.check(lib.td_reduce_dP(native.ptr(dP_part), n_src, B, H, W, native.ptr(dP), st), "td_reduce_dP")
         return d_disp, dP, None, None, None, None, None, None, None, None, None
