@@ -73,6 +73,37 @@ def test_gemm_and_epilogue_statistics(B, Hi, Wi, K, N, stride, groups):
     assert torch.allclose(sums[..., 1], ref_q, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,Hi,Wi,K,N,stride,groups", SHAPES)
+@pytest.mark.parametrize("dw_dtype", [torch.bfloat16, torch.float32])
+def test_weight_gradient_kernel(B, Hi, Wi, K, N, stride, groups, dw_dtype):
+    """td_conv1x1_wgrad (MFMA over the pixel index through ds_read_b64_tr_b16, ordered slab sum) against the fp64 product of
+    the same bf16 operands.  The inputs are ASYMMETRIC on purpose (x carries a per-channel ramp, dy a different one): a
+    transposed or permuted operand map cannot pass.  fp32 slab: 2e-4 of the largest element (fp32 accumulation over up to
+    276 480 pixels); bf16 output: plus its rounding, 2^-8 relative."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native
+    from tripled_amd.ops import _raw
+    lib = native.load()
+    g = torch.Generator().manual_seed(3)
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    M = B * Ho * Wo
+    x = (torch.randn(B, K, Hi, Wi, generator=g) + torch.linspace(-1, 1, K).view(1, K, 1, 1)).to(torch.bfloat16)
+    dy = (torch.randn(B, N, Ho, Wo, generator=g) * torch.linspace(0.2, 2.0, N).view(1, N, 1, 1)).to(torch.bfloat16)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dw = torch.full((N, K, 1, 1), float("nan"), device="cuda", dtype=dw_dtype)
+    ws = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), device="cuda")
+    native.check(lib.td_conv1x1_wgrad(_raw(dyd), _raw(xd), M, K, N, Hi, Wi, stride, native.DTYPE_CODES[dw_dtype], _raw(dw), native.ptr(ws),
+                                      native.stream()), "td_conv1x1_wgrad")
+    torch.cuda.synchronize()
+    xs = x[:, :, ::stride, ::stride].permute(0, 2, 3, 1).reshape(M, K).double()
+    ref = dy.permute(0, 2, 3, 1).reshape(M, N).double().t() @ xs
+    got = dw.double().cpu().reshape(N, K)
+    assert bool(torch.isfinite(got).all())
+    tol = 2e-4 * float(ref.abs().max()) + (2.0 ** -8 * ref.abs() if dw_dtype == torch.bfloat16 else 0.0)
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
+
+
 @pytest.mark.parametrize("B,Hi,Wi,K,N,stride,groups", [SHAPES[1], SHAPES[3], SHAPES[6], SHAPES[9], SHAPES[10], SHAPES[11]])
 @pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
 def test_conv_bn_act_forward_backward_vs_fp32(B, Hi, Wi, K, N, stride, groups, relu, with_res):

@@ -213,6 +213,138 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
 #undef CV_LD
 #undef CV_ST
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution:  dW[n, k] = sum_m dY[m, n] * X[src(m), k]   (reference: autograd of
+// nn.Conv2d(kernel_size=1) in resnet.py:51-86).  The reduction runs over the pixel index m, i.e. over the ROWS of both
+// channels-last matrices, so both MFMA operands are needed "8 consecutive rows of one column" per lane: the tiles go to
+// LDS as they lie in memory (rows of 64 channels, 16-byte stores, pitch = 192 bytes) and are read back through the
+// hardware transpose ds_read_b64_tr_b16 (two reads per 32x32x16 operand; pitch = 192 mod 256 makes the 32 lanes of a half hit
+// 64 distinct banks).  M is cut into P row ranges (the grid is (N/64) x (K/64) x P workgroups), every workgroup writes its
+// 64 x 64 fp32 partial tile and conv1x1_wgrad_reduce_kernel adds the P slabs in order: deterministic, no atomics, no
+// zero-fill / cast passes around it (MIOpen's split-K weight-gradient kernels need both).
+constexpr int WG_T = 64;                         // output tile (n x k) and the reduction rows per stage
+constexpr int WG_PITCH = WG_T * 2 + 64;          // bytes per LDS row
+
+typedef __attribute__((ext_vector_type(4))) short cv_s16x4;
+
+__device__ __forceinline__ cv_bf16x8 wg_frag(const unsigned char* tile, int col0, int ks, int lane) {
+  // operand fragment of the 32 columns col0.. of a [64 rows][64 cols] bf16 tile for reduction rows 16 ks .. 16 ks + 15:
+  // lane l -> column col0 + (l & 31), rows 16 ks + 8 (l >> 5) + 0..7
+  const int g = lane >> 4, i = lane & 15;
+  const int row = 16 * ks + 8 * (g >> 1) + (i >> 2);
+  const unsigned char* p = tile + row * WG_PITCH + (col0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+  typedef __attribute__((address_space(3))) cv_s16x4* lds_ptr;
+  const cv_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const cv_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * WG_PITCH));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(cv_bf16x8, v);
+}
+
+__global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_kernel(
+    const __hip_bfloat16* __restrict__ dy, const __hip_bfloat16* __restrict__ x, float* __restrict__ part, long long M, int K, int N,
+    int rows_per_split, int tiles_n, int tiles_k, ConvRows geom) {
+  constexpr int TILE_BYTES = WG_T * WG_PITCH, STAGE = 2 * TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wk = wid & 1;
+  const int nt = blockIdx.x % tiles_n, kt = (blockIdx.x / tiles_n) % tiles_k, sp = blockIdx.x / (tiles_n * tiles_k);
+  const int n0 = nt * WG_T, k0 = kt * WG_T;
+  const long long m_lo = (long long)sp * rows_per_split;
+  const long long m_hi = (m_lo + rows_per_split < M) ? m_lo + rows_per_split : M;
+  const int nstage = (int)((m_hi - m_lo + WG_T - 1) / WG_T);
+
+  // staging: thread t moves 16-byte chunk (t & 7) of rows (t >> 3) and (t >> 3) + 32 of both tiles
+  const int lc = tid & 7, lr = tid >> 3;
+  uint4 ry0, ry1, rx0, rx1;
+#define WG_LOAD(st)                                                                                             \
+  {                                                                                                             \
+    const long long r0 = m_lo + (long long)(st) * WG_T + lr, r1 = r0 + 32;                                      \
+    const uint4 z = make_uint4(0, 0, 0, 0);                                                                     \
+    ry0 = r0 < m_hi ? *reinterpret_cast<const uint4*>(dy + r0 * N + n0 + lc * 8) : z;                           \
+    ry1 = r1 < m_hi ? *reinterpret_cast<const uint4*>(dy + r1 * N + n0 + lc * 8) : z;                           \
+    rx0 = r0 < m_hi ? *reinterpret_cast<const uint4*>(x + cv_src_row(r0, geom) * (long long)K + k0 + lc * 8) : z; \
+    rx1 = r1 < m_hi ? *reinterpret_cast<const uint4*>(x + cv_src_row(r1, geom) * (long long)K + k0 + lc * 8) : z; \
+  }
+#define WG_WRITE(buf)                                                                            \
+  {                                                                                              \
+    unsigned char* b_ = lds + (buf) * STAGE;                                                     \
+    *reinterpret_cast<uint4*>(b_ + lr * WG_PITCH + lc * 16) = ry0;                               \
+    *reinterpret_cast<uint4*>(b_ + (lr + 32) * WG_PITCH + lc * 16) = ry1;                        \
+    *reinterpret_cast<uint4*>(b_ + TILE_BYTES + lr * WG_PITCH + lc * 16) = rx0;                  \
+    *reinterpret_cast<uint4*>(b_ + TILE_BYTES + (lr + 32) * WG_PITCH + lc * 16) = rx1;           \
+  }
+  cv_f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  WG_LOAD(0)
+  WG_WRITE(0)
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    if (more) WG_LOAD(st + 1)
+    const unsigned char* ty = lds + (st & 1) * STAGE;
+    const unsigned char* tx = ty + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < WG_T / 16; ++ks) {
+      const cv_bf16x8 fa = wg_frag(ty, wn * 32, ks, lane);      // A[i = n][r = m]
+      const cv_bf16x8 fb = wg_frag(tx, wk * 32, ks, lane);      // B[r = m][j = k]
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    if (more) WG_WRITE((st + 1) & 1)
+    __syncthreads();
+  }
+#undef WG_LOAD
+#undef WG_WRITE
+  // D[i = n][j = k]: lane -> k = k0 + 32 wk + (lane & 31), register r -> n = n0 + 32 wn + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* out = part + ((size_t)sp * N + n0 + wn * 32 + 4 * (lane >> 5)) * K + k0 + wk * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2)) * K] = acc[r];
+}
+
+// dW = sum over the P slabs, in a fixed order: a block owns 64 consecutive elements (16 float4 columns) and splits the slabs
+// over 16 lanes groups (p = g, g + 16, ...), combined through LDS -- a 64 x 64 weight with 360 slabs is 64 blocks of 23-deep
+// loops instead of 4 blocks of 360-deep ones.
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void conv1x1_wgrad_reduce_kernel(const float* __restrict__ part, int P, long long NK, T* __restrict__ dw) {
+  __shared__ float4 red[16][16];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long long i = ((long long)blockIdx.x * 16 + c) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < NK) {
+    for (int p = g; p < P; p += 16) {
+      const float4 b = *reinterpret_cast<const float4*>(part + (size_t)p * NK + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+  }
+  red[g][c] = a;
+  __syncthreads();
+  if (g == 0 && i < NK) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 b = red[j][c];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if constexpr (sizeof(T) == 2) {
+      uint2 o;
+      o.x = (unsigned)f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+      o.y = (unsigned)f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+      *reinterpret_cast<uint2*>(dw + i) = o;
+    } else {
+      *reinterpret_cast<float4*>(dw + i) = a;
+    }
+  }
+}
+
+static inline int wg_splits(long long M, int K, int N) {
+  const long long tiles = (long long)(N / WG_T) * (K / WG_T);
+  long long p = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU
+  const long long by_rows = (M + 4 * WG_T - 1) / (4 * WG_T);   // at least four stages per workgroup
+  if (p > by_rows) p = by_rows;
+  if (p > 512) p = 512;
+  return (int)(p < 1 ? 1 : p);
+}
+
 struct ConvTile { int bm, bn; };
 
 static inline ConvTile cv_pick_tile(long long Mg, int G, int N) {
@@ -261,4 +393,40 @@ extern "C" int td_conv1x1_fwd(const void* x, const void* w, long long M, int gro
   if (t.bm == 128 && t.bn == 128) return td::cv_launch<128, 128>(x, w, y, stat_partials, Mg, groups, K, N, geom, st);
   if (t.bm == 128 && t.bn == 64) return td::cv_launch<128, 64>(x, w, y, stat_partials, Mg, groups, K, N, geom, st);
   return td::cv_launch<64, 64>(x, w, y, stat_partials, Mg, groups, K, N, geom, st);
+}
+
+extern "C" long long td_conv1x1_wgrad_workspace_floats(long long M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || K % 64 != 0 || N % 64 != 0) return 0;
+  return (long long)td::wg_splits(M, K, N) * N * K;
+}
+
+extern "C" int td_conv1x1_wgrad(const void* dy, const void* x, long long M, int K, int N, int Hi, int Wi, int stride, int dw_dtype,
+                                void* dw, float* workspace, td_stream_t stream) {
+  if (!dy || !x || !dw || !workspace || M <= 0 || K <= 0 || N <= 0 || K % 64 != 0 || N % 64 != 0 || stride < 1) return TD_ERR_BAD_ARG;
+  if (dw_dtype != TD_DTYPE_BF16 && dw_dtype != TD_DTYPE_F32) return TD_ERR_UNSUPPORTED;
+  td::ConvRows geom = {0, 0, 0, 0, 1};
+  if (stride > 1) {
+    if (Hi <= 0 || Wi <= 0) return TD_ERR_BAD_ARG;
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    if (M % ((long long)Ho * Wo) != 0) return TD_ERR_BAD_ARG;
+    geom = {Wo, Ho * Wo, Wi, Hi * Wi, stride};
+  }
+  if (M * (long long)(K > N ? K : N) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = td::wg_splits(M, K, N);
+  long long rps = (M + P - 1) / P;
+  rps = (rps + td::WG_T - 1) / td::WG_T * td::WG_T;
+  const int P_eff = (int)((M + rps - 1) / rps);          // (<= P: trailing empty ranges are not launched; the reduce reads P_eff slabs)
+  const int tn = N / td::WG_T, tk = K / td::WG_T;
+  hipLaunchKernelGGL(td::conv1x1_wgrad_kernel, dim3((unsigned)(tn * tk * P_eff)), dim3(td::CV_THREADS), 0, st, (const __hip_bfloat16*)dy,
+                     (const __hip_bfloat16*)x, workspace, M, K, N, (int)rps, tn, tk, geom);
+  const long long NK = (long long)N * K;
+  const unsigned blocks = (unsigned)((NK / 4 + 15) / 16);
+  if (dw_dtype == TD_DTYPE_BF16)
+    hipLaunchKernelGGL((td::conv1x1_wgrad_reduce_kernel<__hip_bfloat16>), dim3(blocks), dim3(TD_THREADS), 0, st, (const float*)workspace, P_eff,
+                       NK, (__hip_bfloat16*)dw);
+  else
+    hipLaunchKernelGGL((td::conv1x1_wgrad_reduce_kernel<float>), dim3(blocks), dim3(TD_THREADS), 0, st, (const float*)workspace, P_eff, NK,
+                       (float*)dw);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }

@@ -425,8 +425,16 @@ class _Conv1x1BatchNormAct(torch.autograd.Function):
                                    native.ptr(dbeta), native.ptr(ws), native.stream()), "td_bn_bwd")
         if ctx.has_res and not ctx.relu:
             dres = dy
-        dx, dw, _ = torch.ops.aten.convolution_backward(dyc, x, w, None, [ctx.stride, ctx.stride], [0, 0], [1, 1], False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        dx = dw = None
+        if ctx.needs_input_grad[0]:      # data gradient: MIOpen / CK
+            dx = torch.ops.aten.convolution_backward(dyc, x, w, None, [ctx.stride, ctx.stride], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:      # weight gradient: hand-written MFMA kernel (transposed LDS reads, ordered slab sum)
+            K, Hi, Wi = x.shape[1], x.shape[2], x.shape[3]
+            dw = torch.empty_like(w)
+            wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), device=x.device, dtype=torch.float32)
+            native.check(lib.td_conv1x1_wgrad(_raw(dyc), _raw(x), M, K, N, Hi, Wi, ctx.stride, native.DTYPE_CODES[w.dtype], _raw(dw),
+                                              native.ptr(wsw), native.stream()), "td_conv1x1_wgrad")
         return dx, dw, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None, None, None
 
 
