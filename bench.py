@@ -132,7 +132,7 @@ def build_model(cfg, device, channels_last):
     return model
 
 
-def time_kernel(fn, iters=20, warm=3):
+def time_kernel(fn, iters=50, warm=5):
     for _ in range(warm):
         fn()
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
