@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--top", type=int, default=25)
     ap.add_argument("--last", type=int, default=0, help="only the last N dispatches (steady-state steps after MIOpen's find)")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
+    ap.add_argument("--steady-steps", type=int, default=0, help="only the last N whole training steps (delimited by the identity-term kernel)")
     ap.add_argument("--json", default=None, help="write profiles/mfma.json (stamped with the sources and the workload; bench.py "
                                                  "quotes it only while both still match)")
     ap.add_argument("--steps", type=float, default=1.0, help="training steps covered by the selected dispatches")
@@ -36,7 +37,16 @@ def main():
     recs = []
     for f in files:
         recs += list(csv.DictReader(open(f)))
-    if a.last:
+    if a.steady_steps:
+        # whole steady-state steps: the identity-term kernel (photo_fwd_kernel<*, 0, *>) runs exactly once per training step
+        marks = sorted({int(r["Dispatch_Id"]) for r in recs
+                        if "photo_fwd_kernel" in (r.get("Kernel_Name") or "") and ", 0, " in (r.get("Kernel_Name") or "")})
+        if len(marks) < a.steady_steps + 1:
+            raise SystemExit("not enough steps in the counter file: %d identity kernels" % len(marks))
+        lo, hi = marks[-a.steady_steps - 1], marks[-1]
+        recs = [r for r in recs if lo <= int(r["Dispatch_Id"]) < hi]
+        a.steps = float(a.steady_steps)
+    elif a.last:
         ids = sorted({int(r["Dispatch_Id"]) for r in recs})
         keep = set(ids[-a.last:])
         recs = [r for r in recs if int(r["Dispatch_Id"]) in keep]

@@ -114,8 +114,17 @@ __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, in
   __shared__ float red[2][BN_FIN_PARTS][BN_FIN_CH];
   const int tid = threadIdx.x, c = tid % BN_FIN_CH, part = tid / BN_FIN_CH;
   float a = 0.f, b = 0.f;
-#pragma unroll 4
-  for (int s = part; s < S; s += BN_FIN_PARTS) {
+  // the partial rows were written by other CUs a kernel ago (L2 / fabric latency per load): issue 12 loads before the first add;
+  // the adds keep their order, so the sums are the same bit for bit
+  int s = part;
+  for (; s + 11 * BN_FIN_PARTS < S; s += 12 * BN_FIN_PARTS) {
+    float2 p[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) p[u] = *reinterpret_cast<const float2*>(ws + ((size_t)(s + u * BN_FIN_PARTS) * C + (size_t)cg * BN_FIN_CH + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 12; ++u) { a += p[u].x; b += p[u].y; }
+  }
+  for (; s < S; s += BN_FIN_PARTS) {
     const float2 p = *reinterpret_cast<const float2*>(ws + ((size_t)s * C + (size_t)cg * BN_FIN_CH + c) * 2);
     a += p.x;
     b += p.y;
