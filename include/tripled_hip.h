@@ -267,6 +267,14 @@ int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const flo
 int td_conv1x1_stat_rows(long long M, int groups, int N);
 int td_conv1x1_fwd(const void* x, const void* w, long long M, int groups, int K, int N, int Hi, int Wi, int stride, void* y,
                    float* stat_partials, td_stream_t stream);
+/* 3x3 convolution (stride 1 or 2, padding 0 or 1) of the ResNet blocks and the decoders as an implicit MFMA GEMM: K = 9 * Cin
+ * walked tap by tap over the channels-last input (the im2col matrix is never formed), same epilogue as td_conv1x1_fwd
+ * (stat_partials: td_conv1x1_stat_rows(B*Ho*Wo, groups, N) row tiles; may be NULL).  Replaces conv2 (+ bn2's statistics pass)
+ * of Bottleneck.forward and the convolutions of BasicBlock.forward (mono/model/mono_fm_joint/resnet.py:30-49, 66-86).
+ *   x [B, Hi, Wi, Cin] bf16 channels-last, w [N, 3, 3, Cin] bf16 (the memory of a channels-last [N, Cin, 3, 3] weight),
+ *   y [B, Ho, Wo, N] bf16; Cin % 8 == 0, N % 64 == 0. */
+int td_conv3x3_fwd(const void* x, const void* w, int B, int groups, int Hi, int Wi, int Cin, int N, int stride, int pad, void* y,
+                   float* stat_partials, td_stream_t stream);
 long long td_conv1x1_wgrad_workspace_floats(long long M, int K, int N);
 int td_conv1x1_wgrad(const void* dy, const void* x, long long M, int K, int N, int Hi, int Wi, int stride, int dw_dtype, void* dw,
                      float* workspace, td_stream_t stream);

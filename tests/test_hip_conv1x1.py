@@ -188,3 +188,39 @@ def test_bottleneck_uses_the_mfma_path_and_matches_miopen():
         networks.FUSED_1X1_OFF = prev
     d = (a.float() - b.float()).abs()
     assert float(d.max()) <= 0.05 and float(d.mean()) < 4e-3, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("B,Hi,Wi,C,N,stride,pad,groups", [(12, 48, 160, 64, 64, 1, 1, 1), (6, 24, 80, 128, 128, 2, 1, 3),
+                                                           (4, 12, 40, 256, 256, 1, 1, 1), (2, 26, 42, 520, 256, 1, 0, 1),
+                                                           (3, 7, 11, 64, 128, 1, 1, 1)])
+def test_conv3x3_implicit_gemm(B, Hi, Wi, C, N, stride, pad, groups):
+    """td_conv3x3_fwd (the 1x1 GEMM's tiles, stages, MFMA block and epilogue with K = 9 * Cin walked tap by tap; zero-filled
+    padding and a zero-filled last partial channel chunk for Cin = 520) against fp32 F.conv2d of the same bf16 operands, and its
+    epilogue statistics against sums over the stored tensor.  Built and measured this round; NOT dispatched by the model: MIOpen's
+    tuned implicit-GEMM kernels are 1.2-1.7x faster on these compute-bound shapes (profiles/r03/conv3x3_bench_v1.json)."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native
+    from tripled_amd.ops import _raw
+    lib = native.load()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, C, Hi, Wi, generator=g) * 0.7 + 0.1).to(torch.bfloat16)
+    w = (torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(torch.bfloat16)
+    Ho, Wo = (Hi + 2 * pad - 3) // stride + 1, (Wi + 2 * pad - 3) // stride + 1
+    M = B * Ho * Wo
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last)
+    y = torch.empty(B, N, Ho, Wo, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    S = lib.td_conv1x1_stat_rows(M, groups, N)
+    part = torch.full((groups, S, N, 2), float("nan"), device="cuda")
+    native.check(lib.td_conv3x3_fwd(_raw(xd), _raw(wd), B, groups, Hi, Wi, C, N, stride, pad, _raw(y), native.ptr(part), native.stream()),
+                 "td_conv3x3_fwd")
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float(), w.float(), stride=stride, padding=pad)
+    got = y.float().cpu()
+    tol = 2.0 ** -8 * ref.abs() + 1e-3 * float(ref.abs().max())
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
+    rows = y.permute(0, 2, 3, 1).reshape(groups, M // groups, N).double()
+    sums = part.double().sum(1).cpu()
+    ref_s, ref_q = rows.sum(1).cpu(), (rows * rows).sum(1).cpu()
+    assert torch.allclose(sums[..., 0], ref_s, rtol=1e-5, atol=1e-3 * float(ref_s.abs().max()) + 1e-6)
+    assert torch.allclose(sums[..., 1], ref_q, rtol=1e-5, atol=1e-6)

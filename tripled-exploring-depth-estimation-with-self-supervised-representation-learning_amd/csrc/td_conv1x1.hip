@@ -19,18 +19,9 @@
 // K-step.  Consecutive block ids are remapped so that the blocks of one XCD walk neighbouring tiles (they share the
 // pixel rows between channel tiles and always share W in that XCD's L2).
 // Roofline: these GEMMs are HBM-bound (K = 64..2048, N = 64..2048 against M up to 276 480): bytes = 2 (M K + N K + M N).
-#include <hip/hip_bf16.h>
-
-#include "td_common.h"
-#include "td_vec8.h"
+#include "td_conv_tile.h"
 
 namespace td {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 cv_bf16x8;
-typedef __attribute__((ext_vector_type(16))) float cv_f32x16;
-
-constexpr int CV_BK = 64;            // K elements per stage (128 bytes per row)
-constexpr int CV_THREADS = 256;
 
 struct ConvRows {                    // output pixel -> input pixel of a strided 1x1 convolution (stride 1: identity)
   int Wo, HoWo, Wi, HiWi, stride;
@@ -44,33 +35,18 @@ __device__ __forceinline__ long long cv_src_row(long long m, const ConvRows& g) 
   return b * g.HiWi + (long long)ho * g.stride * g.Wi + (long long)wo * g.stride;
 }
 
-// byte offset of 16-byte chunk c (0..7) of row r in a [rows][64 bf16] stage
-__device__ __forceinline__ int cv_swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
-
 template <int BM, int BN>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w, __hip_bfloat16* __restrict__ y,
     float* __restrict__ ws, long long Mg, int K, int N, int tiles_per_group, int total_blocks, ConvRows geom) {
-  constexpr int WM = BM / 2, WN = BN / 2;          // wave tile: WM pixels x WN channels
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int PITCH = BN * 2 + 8;                // epilogue image row pitch (bytes): 8-byte stores conflict-free
-  constexpr int CX = BN / 8;                       // 8-channel vectors per pixel row of the tile
-  constexpr int RSTEP = CV_THREADS / CX;           // pixel rows covered per pass of the store loop
-  constexpr int RED_BYTES = 2 * RSTEP * (BN + 1) * 4;
-  constexpr int IMG_BYTES = BM * PITCH;
-  constexpr int LDS_BYTES = (2 * STAGE > IMG_BYTES + RED_BYTES) ? 2 * STAGE : IMG_BYTES + RED_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  using T = CvTile<BM, BN>;
+  constexpr int A_BYTES = T::A_BYTES, STAGE = T::STAGE, TN = T::TN, TM = T::TM;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[T::LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
 
-  // XCD-aware tile order: blocks b and b + 8 share an XCD (round-robin dispatch), so XCD x walks a contiguous run of tiles
-  int L;
-  {
-    const int b = blockIdx.x, xcd = b & 7, q = total_blocks >> 3, r = total_blocks & 7;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  const int L = cv_xcd_tile(blockIdx.x, total_blocks);
   const int NT = N / BN;
   const int nt = L % NT, mt = L / NT;
   const int grp = mt / tiles_per_group, s = mt - grp * tiles_per_group;
@@ -114,13 +90,13 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     if (NB > 2) { CV_ST(base_ + A_BYTES, 2, rb2); CV_ST(base_ + A_BYTES, 3, rb3); } \
   }
 
-  cv_f32x16 acc[TN][TM];
+  CvAcc<BM, BN> acc;
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
 
   const int nk = K / CV_BK;
   CV_LOAD_GLOBAL(0)
@@ -131,81 +107,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     if (more) CV_LOAD_GLOBAL(kt + 1)
     const unsigned char* sa = lds + (kt & 1) * STAGE;
     const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < CV_BK / 16; ++kk) {
-      cv_bf16x8 fw[TN], fx[TM];
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        fw[i] = __builtin_bit_cast(cv_bf16x8, *reinterpret_cast<const uint4*>(sb + cv_swz(wn * WN + i * 32 + l31, 2 * kk + h)));
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        fx[j] = __builtin_bit_cast(cv_bf16x8, *reinterpret_cast<const uint4*>(sa + cv_swz(wm * WM + j * 32 + l31, 2 * kk + h)));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-    }
+    cv_stage_mfma<BM, BN>(acc, sa, sb, wm, wn, l31, h);
     if (more) CV_WRITE_LDS((kt + 1) & 1)
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> bf16 image [pixel][channel] in LDS (the stages are free after the last barrier)
-  unsigned char* img = lds;
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // registers 4g..4g+3 of lane (l31, h): channels wn*WN + 32 i + 8 g + 4 h + {0..3} of pixel wm*WM + 32 j + l31
-        uint2 p;
-        p.x = (unsigned)f2bf(acc[i][j][4 * g + 0]) | ((unsigned)f2bf(acc[i][j][4 * g + 1]) << 16);
-        p.y = (unsigned)f2bf(acc[i][j][4 * g + 2]) | ((unsigned)f2bf(acc[i][j][4 * g + 3]) << 16);
-        const int pix = wm * WM + j * 32 + l31, ch = wn * WN + i * 32 + 8 * g + 4 * h;
-        *reinterpret_cast<uint2*>(img + pix * PITCH + ch * 2) = p;
-      }
-  __syncthreads();
-
-  // ---- image -> global in whole pixel rows (16 bytes per lane), and the BatchNorm partial sums of this tile
-  const int cx = tid % CX, ry = tid / CX;
-  float sa8[8], sq8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { sa8[e] = 0.f; sq8[e] = 0.f; }
-#pragma unroll 4
-  for (int r = ry; r < BM; r += RSTEP) {
-    const uint2 lo = *reinterpret_cast<const uint2*>(img + r * PITCH + cx * 16);
-    const uint2 hi = *reinterpret_cast<const uint2*>(img + r * PITCH + cx * 16 + 8);
-    if (r < rows_valid) {
-      *reinterpret_cast<uint4*>(y + (row0 + r) * (long long)N + n0 + cx * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      if (ws) {
-        const unsigned wv[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v0 = bf2f((unsigned short)(wv[e] & 0xffff)), v1 = bf2f((unsigned short)(wv[e] >> 16));
-          sa8[2 * e] += v0;
-          sq8[2 * e] = fmaf(v0, v0, sq8[2 * e]);
-          sa8[2 * e + 1] += v1;
-          sq8[2 * e + 1] = fmaf(v1, v1, sq8[2 * e + 1]);
-        }
-      }
-    }
-  }
-  if (ws) {
-    float* red = reinterpret_cast<float*>(lds + IMG_BYTES);        // [2][RSTEP][BN + 1], behind the image
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[(0 * RSTEP + ry) * (BN + 1) + cx * 8 + e] = sa8[e];
-      red[(1 * RSTEP + ry) * (BN + 1) + cx * 8 + e] = sq8[e];
-    }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, c = tid - which * BN;
-      float t = 0.f;
-#pragma unroll 8
-      for (int j = 0; j < RSTEP; ++j) t += red[(which * RSTEP + j) * (BN + 1) + c];
-      ws[(((long long)grp * tiles_per_group + s) * N + n0 + c) * 2 + which] = t;
-    }
-  }
+  cv_epilogue<BM, BN>(acc, lds, y, ws, row0, rows_valid, n0, N, (long long)grp * tiles_per_group + s, tid, wm, wn, l31, h);
 }
 
 #undef CV_LOAD_GLOBAL
@@ -343,15 +250,6 @@ static inline int wg_splits(long long M, int K, int N) {
   if (p > by_rows) p = by_rows;
   if (p > 512) p = 512;
   return (int)(p < 1 ? 1 : p);
-}
-
-struct ConvTile { int bm, bn; };
-
-static inline ConvTile cv_pick_tile(long long Mg, int G, int N) {
-  auto blocks = [&](int bm, int bn) { return (long long)G * ((Mg + bm - 1) / bm) * (N / bn); };
-  if (N % 128 == 0 && blocks(128, 128) >= 448) return {128, 128};
-  if (blocks(128, 64) >= 448) return {128, 64};
-  return {64, 64};
 }
 
 template <int BM, int BN>
