@@ -122,6 +122,16 @@ def main():
                                           native.ptr(idloss), native.ptr(noise), B, H, W, hs, ws, 0.1, 100.0,
                                           native.ptr(argmin), None, None, native.ptr(part), native.ptr(coef), st), "fwd")
 
+        def fwd_nocoef():      # inference / validation form: no SSIM-adjoint coefficient field
+            native.check(lib.td_photo_fwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+                                          native.ptr(idloss), native.ptr(noise), B, H, W, hs, ws, 0.1, 100.0,
+                                          native.ptr(argmin), None, None, native.ptr(part), None, st), "fwd")
+
+        def fwd_nomask():      # no auto-mask terms (MODE 1), coefficients on
+            native.check(lib.td_photo_fwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+                                          None, None, B, H, W, hs, ws, 0.1, 100.0,
+                                          native.ptr(argmin), None, None, native.ptr(part), native.ptr(coef), st), "fwd")
+
         def bwd():
             native.check(lib.td_photo_bwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
                                           native.ptr(argmin), native.ptr(coef), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
@@ -145,7 +155,7 @@ def main():
                                            native.ptr(d_disp), 0, st), "smb")
 
         fwd()
-        for name, fn in (("fwd", fwd), ("bwd", bwd), ("adjoint", adj), ("reduce", red), ("smooth_fwd", smf),
+        for name, fn in (("fwd", fwd), ("fwd_nocoef", fwd_nocoef), ("fwd_nomask", fwd_nomask), ("bwd", bwd), ("adjoint", adj), ("reduce", red), ("smooth_fwd", smf),
                          ("smooth_bwd", smb)):
             if want(name):
                 res["%s_s%d" % (name, s)] = timeit(fn, args.iters)
