@@ -634,13 +634,14 @@ def main():
                 line["roofline_conv"]["pmc"] = None
                 line["roofline_conv"]["pmc_note"] = why
             elif world == 1:
-                # PMC evidence (separate rocprofv3 --pmc pass): MFMA-busy cycles of one step, summed over
-                # the 1024 SIMDs; one busy cycle = 1024 bf16 FLOP, so this is the EXECUTED matrix work of the step
+                # PMC evidence (separate rocprofv3 --pmc pass): MFMA-busy cycles of one step, summed over the 1024 SIMDs.
+                # A busy cycle is 1024 bf16 FLOP only for the 32x32x16 / 16x16x32 instructions (the hand-written kernels); MIOpen's
+                # igemm kernels issue the half-rate 32x32x8 form, so the count is a utilisation figure, not a FLOP count.
                 busy = mf["mfma_busy_cycles_per_step"]
                 line["roofline_conv"]["pmc"] = {
                     "mfma_busy_frac_of_step": round(busy / (ms * 1e-3 * mf["clock_ghz"] * 1e9 * mf["simds"]), 4),
-                    "executed_tflop_per_step": round(busy * 1024 / 1e12, 2),
-                    "mfma_util_inside_conv_kernels": mf["mfma_util_conv_kernels"], "source": mf["source"]}
+                    "mfma_util_inside_conv_kernels": mf["mfma_util_conv_kernels"],
+                    "mfma_util_inside_td_conv1x1": mf.get("mfma_util_td_conv1x1"), "source": mf["source"], "stamp": mf["_stamp"]}
         if world == 1 and not args.no_cpu_baseline:
             del model, step, graph, graph_b, graphed_step, run
             torch.cuda.empty_cache()
