@@ -153,15 +153,17 @@ def roofline_of_hot_kernels(cfg, batch):
     m = cfg.model
     B, H, W = m["imgs_per_gpu"], m["height"], m["width"]
     dev = batch["K"].device
-    tgt = batch[("color", 0, 0)].contiguous()
-    srcs = [batch[("color", f, 0)].contiguous() for f in m["frame_ids"][1:]]
+    from tripled_amd import ops
+    frames = ops.pack_frames(batch[("color", 0, 0)], [batch[("color", f, 0)] for f in m["frame_ids"][1:]])     # RGBX pixels
+    tgt, srcs = frames.tgt, list(frames.srcs)
+    tgt_p, sp_p = frames.tgt_planar, native.ptr_array(frames.srcs_planar)      # td_photo_bwd reads the NCHW frames
     n_src = len(srcs)
     invK = batch["inv_K"].contiguous()
     g = torch.Generator(device="cpu").manual_seed(5)
     T = torch.eye(4).repeat(B, 1, 1)
     T[:, :3, 3] = 0.004 * torch.randn(B, 3, generator=g)      # a few pixels of parallax, like real ego-motion
     P = torch.stack([torch.matmul(batch["K"].cpu(), T)[:, :3, :]] * n_src, 0).contiguous().to(dev)
-    idloss = torch.empty(B, n_src, H, W, device=dev)
+    idloss = torch.empty(B, H, W, n_src, device=dev)
     noise = torch.randn(n_src, B, H, W, device=dev)
     argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
     coef = torch.empty(B, 9, H, W, device=dev)
@@ -186,7 +188,7 @@ def roofline_of_hot_kernels(cfg, batch):
                                           native.ptr(argmin), None, None, native.ptr(part), native.ptr(coef), st), "fwd")
 
         def bwd():
-            native.check(lib.td_photo_bwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+            native.check(lib.td_photo_bwd(native.ptr(tgt_p), sp_p, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
                                           native.ptr(argmin), native.ptr(coef), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
                                           0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
 
@@ -224,10 +226,11 @@ def loss_path_time(cfg, batch, iters=20):
         for d in disps:
             d.grad = None
         P.grad = None
-        idloss = ops.photo_identity(tgt, srcs)
+        frames = ops.pack_frames(tgt, srcs)                  # once per step, as HipLossBackend.begin_step does
+        idloss = ops.photo_identity(frames)
         total = 0.0
         for i, s in enumerate(scales):
-            loss, _, _ = ops.photometric_scale_loss(disps[i], P, tgt, srcs, invK, idloss, noise[i], 0.1, 100.0, len(scales))
+            loss, _, _ = ops.photometric_scale_loss(disps[i], P, frames, None, invK, idloss, noise[i], 0.1, 100.0, len(scales))
             img = ops.area_downsample(tgt, H >> (s + 1), W >> (s + 1))
             total = total + loss + ops.smooth_loss(disps[i], img, True, 1e-3 / (2 ** s) / len(scales))
         total.backward()

@@ -9,7 +9,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
- *   - tensors are dense, NCHW, fp32, row-major (x fastest), exactly as the reference holds them;
+ *   - tensors are dense, NCHW, fp32, row-major (x fastest), exactly as the reference holds them -- except the colour
+ *     frames of the photometric FORWARD entry points (td_photo_identity / td_photo_fwd), which are RGBX pixels [B,H,W,4]
+ *     produced from the reference's [B,3,H,W] tensors by td_pack_rgbx (one 16-byte load per pixel or bilinear tap: the
+ *     forward is bound by the number of memory instructions in flight, not by bytes); td_photo_bwd reads the NCHW frames;
  *   - the caller owns every buffer; the library allocates nothing and keeps no global state;
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream); no call synchronises, so every call is legal inside hipGraph capture;
@@ -28,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 1
+#define TD_ABI_VERSION 2      /* 2: td_photo_identity / td_photo_fwd take RGBX frames, idloss is [B,H,W,n_src], d_up has one plane per frame */
 #define TD_MAX_SRC 4
 
 #define TD_OK 0
@@ -49,6 +52,9 @@ const char* td_last_hip_error(void);
 int td_photo_num_blocks(int B, int H, int W);
 int td_photo_bwd_num_blocks(int B, int H, int W);
 
+/* [B,3,H,W] fp32 colour frame -> RGBX [B,H,W,4] (x = 0), the frame format of td_photo_identity / td_photo_fwd. */
+int td_pack_rgbx(const float* img, int B, int H, int W, float* out, td_stream_t stream);
+
 /*
  * Identity (auto-mask) photometric term, scale independent:
  *   idloss[b, i, y, x] = 0.85 * mean_c SSIM(src_i, tgt) + 0.15 * mean_c sqrt((tgt - src_i)^2 + 1e-6)
@@ -56,9 +62,9 @@ int td_photo_bwd_num_blocks(int B, int H, int W);
  * mono/model/mono_fm_joint_inpaint/net.py:101-106 (SSIM: mono/model/mono_fm_joint/layers.py:85-107,
  * robust_l1 + weights: mono/model/mono_fm_joint/net.py:59-71).  The reference recomputes it per
  * scale; it does not depend on the scale, so it is computed once per step here.
- *   tgt     [B,3,H,W]
- *   src     host array of n_src device pointers, each [B,3,H,W]
- *   idloss  [B,n_src,H,W] (out)
+ *   tgt     [B,H,W,4] RGBX (td_pack_rgbx of the reference's [B,3,H,W] frame)
+ *   src     host array of n_src device pointers, each [B,H,W,4] RGBX
+ *   idloss  [B,H,W,n_src] (out): the terms of a pixel are adjacent (td_photo_fwd reads them with one load)
  */
 int td_photo_identity(const float* tgt, const float* const* src, int n_src,
                       int B, int H, int W, float* idloss, td_stream_t stream);
@@ -74,10 +80,11 @@ int td_photo_identity(const float* tgt, const float* const* src, int n_src,
  *   compute_reprojection_loss (SSIM + robust L1)    mono/model/mono_fm_joint/net.py:67-71
  *   the automask + torch.cat + torch.min block      mono/model/mono_fm_joint_inpaint/net.py:101-117
  *
+ *   tgt, src  RGBX frames as for td_photo_identity
  *   disp      [B,1,hs,ws]  sigmoid disparity of this scale (any hs<=H, ws<=W)
  *   P         [n_src,B,3,4]  (K @ T_i)[:, :3, :]  -- formed by the caller (tiny matmul, keeps autograd to T)
  *   invK      [B,4,4]  (only the upper-left 3x3 block is read, as in the reference)
- *   idloss    [B,n_src,H,W] from td_photo_identity, or NULL to disable automasking
+ *   idloss    [B,H,W,n_src] from td_photo_identity, or NULL to disable automasking
  *   noise     [n_src,B,H,W] standard-normal draws (scaled by 1e-5 inside, net.py:105) or NULL
  *   argmin    [B,H,W] uint8 (out): index into the candidate list (reference: int64 "min_index")
  *   warped    [n_src,B,3,H,W] (out, nullable): the warped sources, outputs[("color", f, s)]

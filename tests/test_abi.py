@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     import tripled_amd  # noqa: F401
     from tripled_amd import native
     lib = native.load()
-    assert lib.td_abi_version() == 1
+    assert lib.td_abi_version() == 2
     # wave tasks of 62 columns x R rows, R picked so that the tasks fill the 2048 resident wave slots in one round
     assert lib.td_photo_num_blocks(12, 192, 640) == 12 * 14 * 11      # R = 14 (even): 1848 tasks
     assert lib.td_photo_bwd_num_blocks(12, 192, 640) == 12 * 11 * 11  # R = 18: 1452 strip tasks x 2 frames = 2904 waves (3 per SIMD: 3072 slots)

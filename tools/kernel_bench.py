@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--W", type=int, default=640)
     ap.add_argument("--only", default="")
     ap.add_argument("--adversarial", action="store_true", help="i.i.d. random frames and large random poses")
+    ap.add_argument("--flat-disp", action="store_true", help="constant disparity at every scale (separates the cost of the disparity's "
+                                                             "detail -- gather coherence -- from the cost of its resolution)")
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else None
     lib = native.load()
@@ -50,6 +52,10 @@ def main():
         tgt = torch.rand_like(tgt)
         srcs = [torch.rand_like(s) for s in srcs]
     n_src = 2
+    from tripled_amd import ops
+    frames = ops.pack_frames(tgt, srcs)                      # RGBX pixels: what the photometric kernels read
+    tgt, srcs = frames.tgt, list(frames.srcs)
+    tgt_p, sp_p = frames.tgt_planar, native.ptr_array(frames.srcs_planar)      # td_photo_bwd reads the NCHW frames
     invK = batch["inv_K"].contiguous()
     g = torch.Generator().manual_seed(5)
     Ts = []
@@ -59,7 +65,7 @@ def main():
         T[:, :3, 3] = (0.5 if args.adversarial else 0.004) * torch.randn(B, 3, generator=g)
         Ts.append(T)
     P = torch.stack([torch.matmul(batch["K"].cpu(), T)[:, :3, :] for T in Ts], 0).contiguous().to(dev)
-    idloss = torch.empty(B, n_src, H, W, device=dev)
+    idloss = torch.empty(B, H, W, n_src, device=dev)
     noise = torch.randn(n_src, B, H, W, device=dev)
     argmin = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
     coef = torch.empty(B, 9, H, W, device=dev)
@@ -109,6 +115,8 @@ def main():
             low = torch.rand(B, 1, max(hs // 8, 2), max(ws // 8, 2), device=dev)
             disp = (0.3 + 0.4 * torch.nn.functional.interpolate(low, size=(hs, ws), mode="bilinear",
                                                                 align_corners=False)).contiguous()
+        if args.flat_disp:
+            disp = torch.full_like(disp, 0.5)
         d_disp = torch.empty_like(disp)
         img = torch.rand(B, 3, hs, ws, device=dev)
         mean = torch.empty(B, device=dev)
@@ -133,7 +141,7 @@ def main():
                                           native.ptr(argmin), None, None, native.ptr(part), native.ptr(coef), st), "fwd")
 
         def bwd():
-            native.check(lib.td_photo_bwd(native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+            native.check(lib.td_photo_bwd(native.ptr(tgt_p), sp_p, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
                                           native.ptr(argmin), native.ptr(coef), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
                                           0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
 

@@ -13,6 +13,7 @@
 #define TD_SSIM_C2 ((float)(0.03 * 0.03))
 #define TD_L1_EPS2 ((float)(1e-3 * 1e-3))
 
+
 namespace td {
 
 int record_launch_error(hipError_t e, const char* what);
@@ -162,6 +163,43 @@ __device__ __forceinline__ TapVals load_taps(const float* __restrict__ plane, in
   v.sw = ld_at(plane, (o1 + (unsigned)t.x0) * 4u);
   v.se = ld_at(plane, (o1 + (unsigned)t.x1) * 4u);
   return v;
+}
+
+// ---- packed frames -------------------------------------------------------------------------------------------------
+// The photometric FORWARD kernels read the target and source frames as RGBX pixels (float4 per pixel, [B, H, W, 4], x = 0; written
+// once per step by td_pack_rgbx): ONE 16-byte load per pixel or bilinear tap instead of three dword loads from the three NCHW planes.
+// The forward keeps 46 loads per row in flight two rows deep against a 6-bit vmcnt (63): it is bound by the NUMBER of vector-memory
+// instructions, not by bytes (gathering one channel instead of three: 61 -> 45 us; RGBX: 61 -> 49 us at scale 0, 217 -> 191 us over
+// the four scales).  Measured and NOT adopted: the same format in the backward (20 instead of 31 loads per row but 126 instead of 106
+// cache lines touched: 202.7 -> 209 us over the four scales; it gains 3 us where the disparity has detail and the dword gathers lose
+// their coalescing, and loses 3 us where the warp is coherent) and the coefficient field as pixels -- [B,H,W,12] (three 16-byte
+// accesses per pixel at a 48-byte stride touch three times the lines of nine coalesced planes: forward 52.0 vs 49.2 us) or
+// [B,3,H,W,4] (contiguous 16-byte accesses: forward unchanged, backward 59.6 vs 57.9 us at scale 0, 50.0 vs 46.6 at scale 3).
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 ld4_at(const float* __restrict__ base, unsigned byte_off) {
+  return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+struct TapVals4 {
+  f4 nw, ne, sw, se;
+};
+
+// the four taps of one RGBX image (pixel = 16 bytes)
+__device__ __forceinline__ TapVals4 load_taps4(const float* __restrict__ img, int W, const Tap& t) {
+  const unsigned o0 = (unsigned)(t.y0 * W), o1 = (unsigned)(t.y1 * W);
+  TapVals4 v;
+  v.nw = ld4_at(img, (o0 + (unsigned)t.x0) * 16u);
+  v.ne = ld4_at(img, (o0 + (unsigned)t.x1) * 16u);
+  v.sw = ld4_at(img, (o1 + (unsigned)t.x0) * 16u);
+  v.se = ld4_at(img, (o1 + (unsigned)t.x1) * 16u);
+  return v;
+}
+
+__device__ __forceinline__ TapVals tap_channel(const TapVals4& v, int c) {      // c: compile-time constant after unrolling
+  TapVals o;
+  o.nw = v.nw[c]; o.ne = v.ne[c]; o.sw = v.sw[c]; o.se = v.se[c];
+  return o;
 }
 
 // ATen accumulation order nw, ne, sw, se.  A tap outside the image has a clamped address and

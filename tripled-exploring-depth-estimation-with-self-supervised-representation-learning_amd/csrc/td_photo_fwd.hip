@@ -28,6 +28,11 @@ namespace td {
 constexpr int FS_COLS = 62;       // output columns per wave task
 constexpr int FS_WAVES = 4;       // independent wave tasks per 256-thread block
 
+__device__ __forceinline__ void store_coef_px(float* __restrict__ coef, int b, unsigned plane, unsigned pix, const float* cv) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) coef[((size_t)b * 9 + i) * plane + pix] = cv[i];      // nine fully coalesced planes [B,9,H,W]
+}
+
 template <int NS>
 struct PhotoFwdArgs {
   const float* tgt;
@@ -58,10 +63,10 @@ struct UpRow {
 template <int NF, int NS>     // NF: frames this wave warps (1 in the split form), NS: all source frames (auto-mask terms)
 struct RowLoads {
   Tap taps[NF];
-  TapVals tv[NF][3];
-  float yv[3];
-  float xv[NF][3];     // identity mode: raw source pixels
-  float idv[NS];       // auto-mask term of the output row this pipeline row completes
+  TapVals4 tv[NF];     // the four RGBX taps of every warped frame
+  f4 yv;               // target pixel (RGBX)
+  f4 xv[NF];           // identity mode: raw source pixels
+  float idv[NS];       // auto-mask term of the output row this pipeline row completes ([B,H,W,NS] interleaved)
   float nz[NS];
 };
 
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
   const bool col_out = live && lane >= 1 && lane <= FS_COLS && x < W;
   const int xo = x < W ? (x < 0 ? 0 : x) : W - 1;    // clamped column for prefetching per-pixel inputs
 
-  const float* tgtb = a.tgt + (size_t)b * 3 * plane;
+  const float* tgtb = a.tgt + (size_t)b * 4 * plane;        // RGBX frames: [B, H, W, 4]
   const float* srcb[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
 #pragma unroll
       for (int i = 1; i < NS; ++i) p = (fw == i) ? a.src[i] : p;
     }
-    srcb[f] = p + (size_t)b * 3 * plane;
+    srcb[f] = p + (size_t)b * 4 * plane;
   }
 
   // ---- per-wave constants: camera, per-lane horizontal up-sampling taps, x part of the rays ----
@@ -145,13 +150,10 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
   auto stage_b = [&](int k, const DispTaps& d, RowLoads<NF, NS>& L) {   // taps + gathers of pipeline row k
     const int qy = reflect1(y0 - 1 + k, H);
     const unsigned off = (unsigned)(qy * W + qx);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) L.yv[c] = ld_at(tgtb + (size_t)c * plane, off * 4u);
+    L.yv = ld4_at(tgtb, off * 16u);
     if (IDENT) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) L.xv[f][c] = ld_at(srcb[f] + (size_t)c * plane, off * 4u);
+      for (int f = 0; f < NF; ++f) L.xv[f] = ld4_at(srcb[f], off * 16u);
     } else {
       const float dd = d.ur.l0 * (ux.l0 * d.v[0] + ux.l1 * d.v[1]) + d.ur.l1 * (ux.l0 * d.v[2] + ux.l1 * d.v[3]);
       const float depth = fast_rcp(a.min_disp + a.disp_range * dd);
@@ -165,15 +167,24 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
         L.taps[f] = project_ray(r0, r1, r2, P[f], depth, W, H, pt, cz);
       }
 #pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) L.tv[f][c] = load_taps(srcb[f] + c * plane, W, L.taps[f]);
+      for (int f = 0; f < NF; ++f) L.tv[f] = load_taps4(srcb[f], W, L.taps[f]);
       if (MODE >= 2) {        // per-pixel inputs of the output row that pipeline row k completes
         int orow = y0 - 2 + k;
         orow = orow < 0 ? 0 : (orow > H - 1 ? H - 1 : orow);
         const unsigned pix = (unsigned)(orow * W + xo);
+        // idloss is [B, H, W, NS]: the NS terms of a pixel are adjacent (one 8 / 16-byte load for two / four frames)
+        const float* idp = a.idloss + ((size_t)b * plane + pix) * NS;
+        if (NS == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(idp);
+          L.idv[0] = v.x; L.idv[NS > 1 ? 1 : 0] = v.y;
+        } else if (NS == 4) {
+          const f4 v = *reinterpret_cast<const f4*>(idp);
 #pragma unroll
-        for (int f = 0; f < NS; ++f) L.idv[f] = ld_at(a.idloss + (size_t)(b * NS + f) * plane, pix * 4u);
+          for (int f = 0; f < NS; ++f) L.idv[f] = v[f & 3];
+        } else {
+#pragma unroll
+          for (int f = 0; f < NS; ++f) L.idv[f] = idp[f];
+        }
         if (MODE >= 3) {
 #pragma unroll
           for (int f = 0; f < NS; ++f) L.nz[f] = ld_at(a.noise + (size_t)(f * a.B + b) * plane, pix * 4u);
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) xw[f][c] = IDENT ? cur.xv[f][c] : blend_taps(cur.tv[f][c], cur.taps[f]);
+      for (int c = 0; c < 3; ++c) xw[f][c] = IDENT ? cur.xv[f][c] : blend_taps(tap_channel(cur.tv[f], c), cur.taps[f]);
     const int r = y0 - 1 + k;
     if (KEEP && !IDENT && k >= 1 && k <= a.rows && r < H && col_out) {
 #pragma unroll
@@ -276,8 +287,13 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
     if (emit_allowed && orow < H && col_out) {
       const unsigned pix = (unsigned)(orow * W + x);
       if (IDENT) {
+        float* idp = a.idloss_out + ((size_t)b * plane + pix) * NS;      // [B, H, W, NS]
+        if (NS == 2) {
+          *reinterpret_cast<float2*>(idp) = make_float2(loss[0], loss[NS > 1 ? 1 : 0]);
+        } else {
 #pragma unroll
-        for (int f = 0; f < NS; ++f) a.idloss_out[(size_t)(b * NS + f) * plane + pix] = loss[f];
+          for (int f = 0; f < NS; ++f) idp[f] = loss[f];
+        }
       } else {
         float best = 0.f;
         int idx = 0;
@@ -303,17 +319,21 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
             // one writer per pixel: the wave whose frame won; wave 0 writes the zeros of an identity win
             const bool won = idx == base + fw;
             if (won || (fw == 0 && idx < base)) {
+              float cv[9];
 #pragma unroll
-              for (int i = 0; i < 9; ++i) a.coef[((size_t)b * 9 + i) * plane + pix] = won ? cfs[0][i] : 0.f;
+              for (int i = 0; i < 9; ++i) cv[i] = won ? cfs[0][i] : 0.f;
+              store_coef_px(a.coef, b, plane, pix, cv);
             }
           } else {
+            float cv[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
               float v = 0.f;
 #pragma unroll
               for (int f = 0; f < NF; ++f) v = (idx == base + f) ? cfs[COEF ? f : 0][i] : v;
-              a.coef[((size_t)b * 9 + i) * plane + pix] = v;
+              cv[i] = v;
             }
+            store_coef_px(a.coef, b, plane, pix, cv);
           }
         }
       }

@@ -138,3 +138,26 @@ extern "C" int td_rgb2lab(const float* rgb, int B, int H, int W, float l_cent, f
                      plane, l_cent, l_norm, ab_norm, lab);
   return td::record_launch_error(hipGetLastError(), "td_rgb2lab");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NCHW [B,3,H,W] colour frame -> RGBX [B,H,W,4] (x = 0): the pixel format the photometric kernels read (td_common.h, "packed
+// frames").  Once per frame and step; 12 B read + 16 B written per pixel.
+namespace td {
+__global__ __launch_bounds__(TD_THREADS) void pack_rgbx_kernel(const float* __restrict__ img, long long plane, long long total,
+                                                              float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * TD_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * TD_THREADS) {
+    const long long b = i / plane, r = i - b * plane;
+    const float* p = img + b * 3 * plane + r;
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(p[0], p[plane], p[2 * plane], 0.f);
+  }
+}
+}  // namespace td
+
+extern "C" int td_pack_rgbx(const float* img, int B, int H, int W, float* out, td_stream_t stream) {
+  if (!img || !out || B <= 0 || H <= 0 || W <= 0) return TD_ERR_BAD_ARG;
+  const long long plane = (long long)H * W, total = (long long)B * plane;
+  long long blocks = (total + TD_THREADS - 1) / TD_THREADS;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(td::pack_rgbx_kernel, dim3((unsigned)blocks), dim3(TD_THREADS), 0, (hipStream_t)stream, img, plane, total, out);
+  return td::record_launch_error(hipGetLastError(), "td_pack_rgbx");
+}

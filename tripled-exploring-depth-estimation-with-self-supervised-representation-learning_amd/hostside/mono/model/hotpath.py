@@ -15,7 +15,7 @@ import torch
 
 
 class StepContext:
-    __slots__ = ("opt", "target", "sources", "K", "inv_K", "idloss", "pyramid", "P_cache")
+    __slots__ = ("opt", "target", "sources", "K", "inv_K", "idloss", "pyramid", "P_cache", "frames")
 
 
 class HipLossBackend:
@@ -33,7 +33,8 @@ class HipLossBackend:
                                "has no CPU implementation in the product package" % target.device)
         ctx = StepContext()
         ctx.opt, ctx.target, ctx.sources, ctx.K, ctx.inv_K = opt, target, list(sources), K, inv_K
-        ctx.idloss = self.ops.photo_identity(target, ctx.sources) if opt.automask else None
+        ctx.frames = self.ops.pack_frames(target, ctx.sources)      # RGBX pixels, once per step for the identity term + every scale
+        ctx.idloss = self.ops.photo_identity(ctx.frames) if opt.automask else None
         ctx.pyramid = {}
         ctx.P_cache = None
         return ctx
@@ -54,7 +55,7 @@ class HipLossBackend:
                 ctx.P_cache = (key, torch.stack([torch.matmul(ctx.K, T)[:, :3, :] for T in Ts], 0))
             P = ctx.P_cache[1]
         loss, argmin, warped = self.ops.photometric_scale_loss(
-            disp, P, ctx.target, ctx.sources, ctx.inv_K, ctx.idloss, noise,
+            disp, P, ctx.frames, None, ctx.inv_K, ctx.idloss, noise,
             opt.min_depth, opt.max_depth, len(opt.scales), keep_warped)
         return loss, argmin, (list(warped.unbind(0)) if keep_warped else None)
 

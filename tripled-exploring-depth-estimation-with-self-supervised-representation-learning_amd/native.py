@@ -22,6 +22,8 @@ _PTRARR = ctypes.POINTER(ctypes.c_void_p)
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _LLARR = ctypes.POINTER(ctypes.c_longlong)     # host arrays
 _IARR = ctypes.POINTER(ctypes.c_int)
+ABI_VERSION = 2      # include/tripled_hip.h: TD_ABI_VERSION
+
 SIGNATURES = {
     "td_abi_version": (_I, []),
     "td_error_string": (ctypes.c_char_p, [_I]),
@@ -31,6 +33,7 @@ SIGNATURES = {
     "td_photo_identity": (_I, [_P, _PTRARR, _I, _I, _I, _I, _P, _P]),
     "td_photo_fwd": (_I, [_P, _PTRARR, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "td_photo_bwd": (_I, [_P, _PTRARR, _I, _P, _P, _P, _P, _P, _I, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "td_pack_rgbx": (_I, [_P, _I, _I, _I, _P, _P]),
     "td_upsample_adjoint": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "td_upsample_adjoint_planes": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "td_reduce_dP": (_I, [_P, _I, _I, _I, _I, _P, _P]),
@@ -119,8 +122,8 @@ def load(path=None):
             raise NativeLibraryError("%s does not export %s" % (path, name)) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.td_abi_version() != 1:
-        raise NativeLibraryError("ABI version mismatch: library %d, binding 1" % lib.td_abi_version())
+    if lib.td_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("ABI version mismatch: library %d, binding %d" % (lib.td_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

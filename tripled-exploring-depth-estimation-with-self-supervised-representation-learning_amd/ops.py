@@ -15,18 +15,51 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def photo_identity(tgt, srcs):
+class PackedFrames:
+    """The target and source frames of a step as RGBX pixels ([B,H,W,4] fp32, x = 0), the format the photometric FORWARD kernels
+    read (csrc/td_common.h "packed frames": one 16-byte load per pixel / bilinear tap instead of three dword loads from the NCHW
+    planes), next to the NCHW originals the backward reads.  Packed once per step by ``pack_frames`` (td_pack_rgbx) and shared by
+    the identity term and the four scales."""
+
+    def __init__(self, tgt, srcs):
+        lib = native.load()
+        self.tgt_planar = _f32c(tgt.detach())                       # td_photo_bwd reads the NCHW frames
+        self.srcs_planar = tuple(_f32c(s.detach()) for s in srcs)
+        self.tgt = self._pack(lib, self.tgt_planar)
+        self.srcs = tuple(self._pack(lib, s) for s in self.srcs_planar)
+        self.shape = (tgt.shape[0], tgt.shape[2], tgt.shape[3])
+
+    @staticmethod
+    def _pack(lib, img):
+        img = _f32c(img.detach())
+        B, C, H, W = img.shape
+        if C != 3:
+            raise ValueError("colour frames are [B,3,H,W], got %s" % (tuple(img.shape),))
+        out = torch.empty(B, H, W, 4, device=img.device, dtype=torch.float32)
+        native.check(lib.td_pack_rgbx(native.ptr(img), B, H, W, native.ptr(out), native.stream()), "td_pack_rgbx")
+        return out
+
+
+def pack_frames(tgt, srcs):
+    return PackedFrames(tgt, srcs)
+
+
+def _frames(tgt, srcs):
+    return tgt if isinstance(tgt, PackedFrames) else PackedFrames(tgt, srcs)
+
+
+def photo_identity(tgt, srcs=None):
     """Auto-mask identity term for every source frame, once per step.
     compute_reprojection_loss(inputs[("color", f, 0)], target) at
-    mono/model/mono_fm_joint_inpaint/net.py:101-104 -> [B, n_src, H, W]."""
+    mono/model/mono_fm_joint_inpaint/net.py:101-104 -> [B, n_src, H, W] (a view: the memory is [B,H,W,n_src], the layout
+    td_photo_fwd reads).  ``tgt``: the [B,3,H,W] target with ``srcs`` the list of sources, or a PackedFrames."""
     lib = native.load()
-    tgt = _f32c(tgt)
-    srcs = [_f32c(s) for s in srcs]
-    B, _, H, W = tgt.shape
-    out = torch.empty(B, len(srcs), H, W, device=tgt.device, dtype=torch.float32)
-    native.check(lib.td_photo_identity(native.ptr(tgt), native.ptr_array(srcs), len(srcs), B, H, W,
+    fr = _frames(tgt, srcs)
+    B, H, W = fr.shape
+    out = torch.empty(B, H, W, len(fr.srcs), device=fr.tgt.device, dtype=torch.float32)
+    native.check(lib.td_photo_identity(native.ptr(fr.tgt), native.ptr_array(fr.srcs), len(fr.srcs), B, H, W,
                                        native.ptr(out), native.stream()), "td_photo_identity")
-    return out
+    return out.permute(0, 3, 1, 2)
 
 
 def area_downsample(img, h, w):
@@ -45,11 +78,11 @@ def area_downsample(img, h, w):
 
 class _PhotometricScaleLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, disp, P, tgt, srcs, invK, idloss, noise, min_depth, max_depth, n_scales, keep_warped):
+    def forward(ctx, disp, P, tgt, srcs, tgt_planar, srcs_planar, invK, idloss, noise, min_depth, max_depth, n_scales, keep_warped):
         lib = native.load()
         disp = _f32c(disp)
         P = _f32c(P)
-        B, _, H, W = tgt.shape
+        B, H, W, _ = tgt.shape                     # RGBX frames [B,H,W,4]
         hs, ws = disp.shape[2], disp.shape[3]
         n_src = len(srcs)
         dev = tgt.device
@@ -69,7 +102,7 @@ class _PhotometricScaleLoss(torch.autograd.Function):
                      "td_photo_fwd")
         inv_count = 1.0 / (float(B) * H * W * n_scales)
         native.check(lib.td_sum_scaled(native.ptr(partial), nblk, inv_count, native.ptr(loss), st), "td_sum_scaled")
-        ctx.save_for_backward(disp, P, tgt, invK, argmin, coef if coef is not None else argmin, *srcs)
+        ctx.save_for_backward(disp, P, tgt_planar, invK, argmin, coef if coef is not None else argmin, *srcs_planar)
         ctx.meta = (min_depth, max_depth, inv_count, idloss is not None, n_src)
         ctx.mark_non_differentiable(argmin)
         if keep_warped:
@@ -82,7 +115,7 @@ class _PhotometricScaleLoss(torch.autograd.Function):
         lib = native.load()
         disp, P, tgt, invK, argmin, coef, *srcs = ctx.saved_tensors
         min_depth, max_depth, inv_count, automask, n_src = ctx.meta
-        B, _, H, W = tgt.shape
+        B, _, H, W = tgt.shape                     # NCHW frames
         hs, ws = disp.shape[2], disp.shape[3]
         dev = tgt.device
         g = _f32c(g_loss.reshape(1))
@@ -100,7 +133,7 @@ class _PhotometricScaleLoss(torch.autograd.Function):
                      "td_upsample_adjoint_planes")
         dP = torch.empty_like(P)
         native.check(lib.td_reduce_dP(native.ptr(dP_part), n_src, B, H, W, native.ptr(dP), st), "td_reduce_dP")
-        return d_disp, dP, None, None, None, None, None, None, None, None, None
+        return d_disp, dP, None, None, None, None, None, None, None, None, None, None, None
 
 
 def photometric_scale_loss(disp, P, tgt, srcs, invK, idloss=None, noise=None, min_depth=0.1,
@@ -108,19 +141,21 @@ def photometric_scale_loss(disp, P, tgt, srcs, invK, idloss=None, noise=None, mi
     """One scale of generate_images_pred + automask + min-reprojection
     (mono/model/mono_fm_joint/net.py:181-194; mono/model/mono_fm_joint_inpaint/net.py:101-117).
 
-    disp [B,1,hs,ws]; P [n_src,B,3,4] = (K @ T)[:, :3, :] per source frame; idloss from
-    photo_identity (None = no automask); noise [n_src,B,H,W] N(0,1) draws or None.
+    disp [B,1,hs,ws]; P [n_src,B,3,4] = (K @ T)[:, :3, :] per source frame; ``tgt`` [B,3,H,W] with ``srcs``, or a PackedFrames
+    (``srcs`` ignored); idloss [B,n_src,H,W] from photo_identity (None = no automask); noise [n_src,B,H,W] N(0,1) draws or None.
     Returns (loss = mean(min)/n_scales, argmin uint8 [B,H,W], warped [n_src,B,3,H,W] or empty).
     """
-    tgt = _f32c(tgt)
-    srcs = tuple(_f32c(s) for s in srcs)
+    fr = _frames(tgt, srcs)                        # RGBX frames (packed here unless the caller packed them once per step)
     invK = _f32c(invK)
     if idloss is not None:
-        idloss = _f32c(idloss)
+        # the kernel reads [B,H,W,n_src]; photo_identity's result is a [B,n_src,H,W] VIEW of exactly that memory
+        idloss = idloss.permute(0, 2, 3, 1)
+        if idloss.dtype != torch.float32 or not idloss.is_contiguous():
+            idloss = idloss.float().contiguous()
     if noise is not None:
         noise = _f32c(noise)
-    return _PhotometricScaleLoss.apply(disp, P, tgt, srcs, invK, idloss, noise, min_depth, max_depth,
-                                       n_scales, keep_warped)
+    return _PhotometricScaleLoss.apply(disp, P, fr.tgt, fr.srcs, fr.tgt_planar, fr.srcs_planar, invK, idloss, noise, min_depth,
+                                       max_depth, n_scales, keep_warped)
 
 
 class _SmoothLoss(torch.autograd.Function):
