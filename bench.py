@@ -173,7 +173,7 @@ def roofline_of_hot_kernels(cfg, batch):
     gs = torch.ones(1, device=dev)
     st = native.stream()
     sp = native.ptr_array(srcs)
-    native.check(lib.td_photo_identity(native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "identity")
+    native.check(lib.td_photo_identity(native.ptr(tgt_p), sp_p, n_src, B, H, W, native.ptr(idloss), native.ptr(tgt), sp, st), "identity")
     out = {}
     px = B * H * W
     for s in (0,):
@@ -226,7 +226,7 @@ def loss_path_time(cfg, batch, iters=20):
         for d in disps:
             d.grad = None
         P.grad = None
-        frames = ops.pack_frames(tgt, srcs)                  # once per step, as HipLossBackend.begin_step does
+        frames = ops.pack_frames(tgt, srcs, pack=False)      # once per step, as HipLossBackend.begin_step does (RGBX by the identity kernel)
         idloss = ops.photo_identity(frames)
         total = 0.0
         for i, s in enumerate(scales):
@@ -372,6 +372,14 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     batch = synthetic_batch(B, H, W, seed=1000 + rank, device=dev, frame_ids=tuple(m["frame_ids"]),
                             coherent=args.frames == "coherent")
+    # the same isolated kernel timing as the `roofline` block, taken BEFORE the training run (idle GPU): reported next to the
+    # after-run figure, which stays the one `roofline.frac` is computed from
+    kern_before = None
+    if rank == 0 and not args.no_roofline:
+        try:
+            kern_before = roofline_of_hot_kernels(cfg, batch)
+        except Exception as e:      # noqa: BLE001 -- auxiliary figure
+            kern_before = {"error": "%s: %s" % (type(e).__name__, e)}
     side = torch.cuda.Stream()
     cap = side if CAPTURE_STREAM == "side" else None
     dispatch.reset()
@@ -612,6 +620,8 @@ def main():
                                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                 "traffic_source": (tblob["_stamp"] if tblob else why),
                                 "launch_us": round(kern[dom]["seconds"] * 1e6, 2),
+                                "before_the_run_us": ({k: round(v["seconds"] * 1e6, 2) for k, v in kern_before.items()}
+                                                      if kern_before and "error" not in kern_before else kern_before),
                                 "all": {k: {"us": round(v["seconds"] * 1e6, 2),
                                             "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in kern.items()}}
             try:

@@ -10,9 +10,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
  *   - tensors are dense, NCHW, fp32, row-major (x fastest), exactly as the reference holds them -- except the colour
- *     frames of the photometric FORWARD entry points (td_photo_identity / td_photo_fwd), which are RGBX pixels [B,H,W,4]
- *     produced from the reference's [B,3,H,W] tensors by td_pack_rgbx (one 16-byte load per pixel or bilinear tap: the
- *     forward is bound by the number of memory instructions in flight, not by bytes); td_photo_bwd reads the NCHW frames;
+ *     frames of td_photo_fwd, which are RGBX pixels [B,H,W,4] produced from the reference's [B,3,H,W] tensors by
+ *     td_photo_identity (as a by-product) or td_pack_rgbx (one 16-byte load per pixel or bilinear tap: the forward is bound
+ *     by the number of memory instructions in flight, not by bytes); td_photo_identity and td_photo_bwd read the NCHW frames;
  *   - the caller owns every buffer; the library allocates nothing and keeps no global state;
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream); no call synchronises, so every call is legal inside hipGraph capture;
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 2      /* 2: td_photo_identity / td_photo_fwd take RGBX frames, idloss is [B,H,W,n_src], d_up has one plane per frame */
+#define TD_ABI_VERSION 2      /* 2: td_photo_fwd takes RGBX frames (td_photo_identity emits them), idloss is [B,H,W,n_src], d_up has one plane per frame */
 #define TD_MAX_SRC 4
 
 #define TD_OK 0
@@ -52,7 +52,7 @@ const char* td_last_hip_error(void);
 int td_photo_num_blocks(int B, int H, int W);
 int td_photo_bwd_num_blocks(int B, int H, int W);
 
-/* [B,3,H,W] fp32 colour frame -> RGBX [B,H,W,4] (x = 0), the frame format of td_photo_identity / td_photo_fwd. */
+/* [B,3,H,W] fp32 colour frame -> RGBX [B,H,W,4] (x = 0), the frame format of td_photo_fwd (when td_photo_identity does not run). */
 int td_pack_rgbx(const float* img, int B, int H, int W, float* out, td_stream_t stream);
 
 /*
@@ -62,12 +62,14 @@ int td_pack_rgbx(const float* img, int B, int H, int W, float* out, td_stream_t 
  * mono/model/mono_fm_joint_inpaint/net.py:101-106 (SSIM: mono/model/mono_fm_joint/layers.py:85-107,
  * robust_l1 + weights: mono/model/mono_fm_joint/net.py:59-71).  The reference recomputes it per
  * scale; it does not depend on the scale, so it is computed once per step here.
- *   tgt     [B,H,W,4] RGBX (td_pack_rgbx of the reference's [B,3,H,W] frame)
- *   src     host array of n_src device pointers, each [B,H,W,4] RGBX
+ *   tgt     [B,3,H,W] (the reference's tensor)
+ *   src     host array of n_src device pointers, each [B,3,H,W]
  *   idloss  [B,H,W,n_src] (out): the terms of a pixel are adjacent (td_photo_fwd reads them with one load)
+ *   tgt_rgbx, src_rgbx (out, both or neither NULL): [B,H,W,4] RGBX copies of the frames (x = 0), the frame format of
+ *           td_photo_fwd -- written from the pixels this kernel reads anyway, which saves the td_pack_rgbx passes
  */
 int td_photo_identity(const float* tgt, const float* const* src, int n_src,
-                      int B, int H, int W, float* idloss, td_stream_t stream);
+                      int B, int H, int W, float* idloss, float* tgt_rgbx, float* const* src_rgbx, td_stream_t stream);
 
 /*
  * Fused per-scale photometric forward.  Replaces, for one scale,
@@ -80,7 +82,7 @@ int td_photo_identity(const float* tgt, const float* const* src, int n_src,
  *   compute_reprojection_loss (SSIM + robust L1)    mono/model/mono_fm_joint/net.py:67-71
  *   the automask + torch.cat + torch.min block      mono/model/mono_fm_joint_inpaint/net.py:101-117
  *
- *   tgt, src  RGBX frames as for td_photo_identity
+ *   tgt, src  RGBX frames [B,H,W,4] (from td_photo_identity's copies or td_pack_rgbx)
  *   disp      [B,1,hs,ws]  sigmoid disparity of this scale (any hs<=H, ws<=W)
  *   P         [n_src,B,3,4]  (K @ T_i)[:, :3, :]  -- formed by the caller (tiny matmul, keeps autograd to T)
  *   invK      [B,4,4]  (only the upper-left 3x3 block is read, as in the reference)

@@ -41,7 +41,7 @@ def test_argument_validation_without_gpu():
     assert lib.td_smooth_num_blocks(12, 96, 320) == 12 * 6 * 5
     # null pointers / bad sizes are rejected before any launch
     assert lib.td_sum_scaled(None, 4, 1.0, None, None) == -1
-    assert lib.td_photo_identity(None, None, 2, 1, 8, 8, None, None) == -1
+    assert lib.td_photo_identity(None, None, 2, 1, 8, 8, None, None, None, None) == -1
     assert lib.td_smooth_finish(None, 1, 8, 8, 1.0, None, None) == -1
     assert b"bad argument" in lib.td_error_string(-1)
     # round-2 entry points: the same contract (nothing is launched on a bad argument)

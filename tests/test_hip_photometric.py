@@ -285,3 +285,21 @@ def test_config_shapes_forward_and_backward(ops, B, H, W, scale):
     # the same outlier pixels (plus those whose sample coordinate rounds across an integer: the bilinear kernel's slope jumps
     # there) enter this 1.3-million-term sum: 1e-2 of the largest element (measured 2.6e-3 / 5.7e-3 / < 2e-3)
     assert rel_err(P.grad, P_ref) < 1e-2
+
+
+def test_identity_kernel_emits_the_rgbx_frames(ops):
+    """td_photo_identity writes the RGBX copies of the frames it reads (the per-scale kernels' input) as a by-product: they must
+    equal td_pack_rgbx's, pixel for pixel, for every frame, and the loss computed from them must equal the loss from packed frames."""
+    B, H, W = 3, 37, 130
+    g = torch.Generator().manual_seed(4)
+    fr = make_triplet(g, B, H, W)
+    tgt, srcs = fr[0].cuda(), [fr[-1].cuda(), fr[1].cuda()]
+    a = ops.pack_frames(tgt, srcs, pack=True)
+    b = ops.pack_frames(tgt, srcs, pack=False)
+    assert not b.packed
+    idl = ops.photo_identity(b)
+    assert b.packed
+    assert torch.equal(a.tgt, b.tgt) and all(torch.equal(x, y) for x, y in zip(a.srcs, b.srcs))
+    want = torch.cat([tgt, torch.zeros(B, 1, H, W, device="cuda")], 1).permute(0, 2, 3, 1)
+    assert torch.equal(b.tgt, want)
+    assert torch.equal(idl, ops.photo_identity(a))

@@ -104,9 +104,9 @@ def main():
         return
     if want("identity"):
         res["identity"] = timeit(lambda: native.check(lib.td_photo_identity(
-            native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "id"), args.iters)
+            native.ptr(tgt_p), sp_p, n_src, B, H, W, native.ptr(idloss), native.ptr(tgt), sp, st), "id"), args.iters)
     else:
-        native.check(lib.td_photo_identity(native.ptr(tgt), sp, n_src, B, H, W, native.ptr(idloss), st), "id")
+        native.check(lib.td_photo_identity(native.ptr(tgt_p), sp_p, n_src, B, H, W, native.ptr(idloss), native.ptr(tgt), sp, st), "id")
     for s in range(4):
         hs, ws = H >> (s + 1), W >> (s + 1)
         if args.adversarial:

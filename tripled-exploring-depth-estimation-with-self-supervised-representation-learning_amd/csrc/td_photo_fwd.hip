@@ -47,6 +47,8 @@ struct PhotoFwdArgs {
   float* min_map;
   float* partial;
   float* idloss_out;   // identity mode only
+  float* pack_tgt;     // identity mode only: RGBX copies of the frames it reads anyway (the per-scale kernels' input format)
+  float* pack_src[NS];
   float* coef;         // [B,9,H,W] SSIM-adjoint coefficients of the selected warped frame (nullable)
   int B, H, W, hs, ws;
   int nstrips, nchunks, ntasks, blocks_per_xcd, rows;
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
   const bool col_out = live && lane >= 1 && lane <= FS_COLS && x < W;
   const int xo = x < W ? (x < 0 ? 0 : x) : W - 1;    // clamped column for prefetching per-pixel inputs
 
-  const float* tgtb = a.tgt + (size_t)b * 4 * plane;        // RGBX frames: [B, H, W, 4]
+  // the per-scale kernels read RGBX frames [B,H,W,4]; the identity-term kernel reads the NCHW frames and WRITES the RGBX copies
+  const float* tgtb = a.tgt + (size_t)b * (IDENT ? 3 : 4) * plane;
   const float* srcb[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
 #pragma unroll
       for (int i = 1; i < NS; ++i) p = (fw == i) ? a.src[i] : p;
     }
-    srcb[f] = p + (size_t)b * 4 * plane;
+    srcb[f] = p + (size_t)b * (IDENT ? 3 : 4) * plane;
   }
 
   // ---- per-wave constants: camera, per-lane horizontal up-sampling taps, x part of the rays ----
@@ -150,11 +153,18 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
   auto stage_b = [&](int k, const DispTaps& d, RowLoads<NF, NS>& L) {   // taps + gathers of pipeline row k
     const int qy = reflect1(y0 - 1 + k, H);
     const unsigned off = (unsigned)(qy * W + qx);
-    L.yv = ld4_at(tgtb, off * 16u);
     if (IDENT) {
 #pragma unroll
-      for (int f = 0; f < NF; ++f) L.xv[f] = ld4_at(srcb[f], off * 16u);
+      for (int c = 0; c < 3; ++c) L.yv[c] = ld_at(tgtb + (size_t)c * plane, off * 4u);
+      L.yv[3] = 0.f;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) L.xv[f][c] = ld_at(srcb[f] + (size_t)c * plane, off * 4u);
+        L.xv[f][3] = 0.f;
+      }
     } else {
+      L.yv = ld4_at(tgtb, off * 16u);
       const float dd = d.ur.l0 * (ux.l0 * d.v[0] + ux.l1 * d.v[1]) + d.ur.l1 * (ux.l0 * d.v[2] + ux.l1 * d.v[3]);
       const float depth = fast_rcp(a.min_disp + a.disp_range * dd);
       const float fy = (float)qy;
@@ -227,6 +237,13 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
           a.warped[(((size_t)(SPLIT ? fw : f) * a.B + b) * 3 + c) * plane + (unsigned)(r * W + x)] = xw[f][c];
     }
     float ss[NF], l1[NF];
+    float own_y[3], own_x[NF][3];                    // the output row's OWN pixels (centre of the window), for the RGBX copies
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      own_y[c] = c_y[c];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) own_x[f][c] = c_x[f][c];
+    }
     float cfs[COEF ? NF : 1][9];                     // (alpha, beta, gamma) per channel of every warped frame of this wave
 #pragma unroll
     for (int f = 0; f < NF; ++f) { ss[f] = 0.f; l1[f] = 0.f; }
@@ -287,6 +304,16 @@ __global__ __launch_bounds__(SPLIT ? (FS_WAVES / NS) * NS * 64 : FS_WAVES * 64, 
     if (emit_allowed && orow < H && col_out) {
       const unsigned pix = (unsigned)(orow * W + x);
       if (IDENT) {
+        if (a.pack_tgt != nullptr) {
+          // the centre values of the window are this output row's own pixels: the RGBX copies cost no extra read
+          f4 v; v[0] = own_y[0]; v[1] = own_y[1]; v[2] = own_y[2]; v[3] = 0.f;
+          *reinterpret_cast<f4*>(a.pack_tgt + ((size_t)b * plane + pix) * 4) = v;
+#pragma unroll
+          for (int f = 0; f < NS; ++f) {
+            f4 u; u[0] = own_x[f][0]; u[1] = own_x[f][1]; u[2] = own_x[f][2]; u[3] = 0.f;
+            *reinterpret_cast<f4*>(a.pack_src[f] + ((size_t)b * plane + pix) * 4) = u;
+          }
+        }
         float* idp = a.idloss_out + ((size_t)b * plane + pix) * NS;      // [B, H, W, NS]
         if (NS == 2) {
           *reinterpret_cast<float2*>(idp) = make_float2(loss[0], loss[NS > 1 ? 1 : 0]);
@@ -405,13 +432,16 @@ template <int NS>
 static int run_fwd(const float* tgt, const float* const* src, const float* disp, const float* P,
                    const float* invK, const float* idloss, const float* noise, int B, int H, int W,
                    int hs, int ws, float min_depth, float max_depth, uint8_t* argmin, float* warped,
-                   float* min_map, float* partial, float* idloss_out, float* coef, bool ident, hipStream_t st) {
+                   float* min_map, float* partial, float* idloss_out, float* coef, bool ident, hipStream_t st,
+                   float* pack_tgt = nullptr, float* const* pack_src = nullptr) {
   PhotoFwdArgs<NS> a;
   a.tgt = tgt;
   for (int i = 0; i < NS; ++i) a.src[i] = src[i];
   a.disp = disp; a.P = P; a.invK = invK; a.idloss = idloss; a.noise = noise;
   a.argmin = argmin; a.warped = warped; a.min_map = min_map; a.partial = partial;
   a.idloss_out = idloss_out;
+  a.pack_tgt = pack_src ? pack_tgt : nullptr;
+  for (int i = 0; i < NS; ++i) a.pack_src[i] = pack_src ? pack_src[i] : nullptr;
   a.coef = coef;
   a.B = B; a.H = H; a.W = W; a.hs = hs; a.ws = ws;
   const double lo = 1.0 / (double)max_depth, hi = 1.0 / (double)min_depth;
@@ -456,24 +486,27 @@ static int dispatch_fwd(const float* tgt, const float* const* src, int n_src, co
                         const float* P, const float* invK, const float* idloss, const float* noise,
                         int B, int H, int W, int hs, int ws, float min_depth, float max_depth,
                         uint8_t* argmin, float* warped, float* min_map, float* partial,
-                        float* idloss_out, float* coef, bool ident, td_stream_t stream) {
+                        float* idloss_out, float* coef, bool ident, td_stream_t stream, float* pack_tgt = nullptr,
+                        float* const* pack_src = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   switch (n_src) {
-    case 1: return td::run_fwd<1>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
-    case 2: return td::run_fwd<2>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
-    case 3: return td::run_fwd<3>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
-    case 4: return td::run_fwd<4>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st);
+    case 1: return td::run_fwd<1>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st, pack_tgt, pack_src);
+    case 2: return td::run_fwd<2>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st, pack_tgt, pack_src);
+    case 3: return td::run_fwd<3>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st, pack_tgt, pack_src);
+    case 4: return td::run_fwd<4>(tgt, src, disp, P, invK, idloss, noise, B, H, W, hs, ws, min_depth, max_depth, argmin, warped, min_map, partial, idloss_out, coef, ident, st, pack_tgt, pack_src);
   }
   return TD_ERR_BAD_ARG;
 }
 
 extern "C" int td_photo_identity(const float* tgt, const float* const* src, int n_src, int B, int H,
-                                 int W, float* idloss, td_stream_t stream) {
+                                 int W, float* idloss, float* tgt_rgbx, float* const* src_rgbx, td_stream_t stream) {
   if (!tgt || !src || !idloss || n_src < 1 || n_src > TD_MAX_SRC || B <= 0) return TD_ERR_BAD_ARG;
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
+  if ((tgt_rgbx == nullptr) != (src_rgbx == nullptr)) return TD_ERR_BAD_ARG;
+  if (src_rgbx) for (int i = 0; i < n_src; ++i) if (!src_rgbx[i]) return TD_ERR_BAD_ARG;
   if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   return dispatch_fwd(tgt, src, n_src, nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, 1, 1,
-                      0.1f, 100.f, nullptr, nullptr, nullptr, nullptr, idloss, nullptr, true, stream);
+                      0.1f, 100.f, nullptr, nullptr, nullptr, nullptr, idloss, nullptr, true, stream, tgt_rgbx, src_rgbx);
 }
 
 extern "C" int td_photo_fwd(const float* tgt, const float* const* src, int n_src, const float* disp,

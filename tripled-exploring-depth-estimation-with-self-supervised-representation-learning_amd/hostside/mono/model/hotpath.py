@@ -33,7 +33,8 @@ class HipLossBackend:
                                "has no CPU implementation in the product package" % target.device)
         ctx = StepContext()
         ctx.opt, ctx.target, ctx.sources, ctx.K, ctx.inv_K = opt, target, list(sources), K, inv_K
-        ctx.frames = self.ops.pack_frames(target, ctx.sources)      # RGBX pixels, once per step for the identity term + every scale
+        # RGBX pixels for the per-scale kernels, once per step: a by-product of the identity-term kernel when it runs
+        ctx.frames = self.ops.pack_frames(target, ctx.sources, pack=not opt.automask)
         ctx.idloss = self.ops.photo_identity(ctx.frames) if opt.automask else None
         ctx.pyramid = {}
         ctx.P_cache = None

@@ -16,49 +16,59 @@ def _f32c(t):
 
 
 class PackedFrames:
-    """The target and source frames of a step as RGBX pixels ([B,H,W,4] fp32, x = 0), the format the photometric FORWARD kernels
-    read (csrc/td_common.h "packed frames": one 16-byte load per pixel / bilinear tap instead of three dword loads from the NCHW
-    planes), next to the NCHW originals the backward reads.  Packed once per step by ``pack_frames`` (td_pack_rgbx) and shared by
-    the identity term and the four scales."""
+    """The target and source frames of a step as RGBX pixels ([B,H,W,4] fp32, x = 0), the format the per-scale photometric
+    forward reads (csrc/td_common.h "packed frames": one 16-byte load per pixel / bilinear tap instead of three dword loads from
+    the NCHW planes), next to the NCHW originals the identity term and the backward read.  The RGBX copies are written by the
+    identity-term kernel from the pixels it reads anyway (``photo_identity``), or by td_pack_rgbx when no identity term runs."""
 
-    def __init__(self, tgt, srcs):
-        lib = native.load()
-        self.tgt_planar = _f32c(tgt.detach())                       # td_photo_bwd reads the NCHW frames
+    def __init__(self, tgt, srcs, pack=True):
+        self.tgt_planar = _f32c(tgt.detach())
         self.srcs_planar = tuple(_f32c(s.detach()) for s in srcs)
-        self.tgt = self._pack(lib, self.tgt_planar)
-        self.srcs = tuple(self._pack(lib, s) for s in self.srcs_planar)
-        self.shape = (tgt.shape[0], tgt.shape[2], tgt.shape[3])
+        if self.tgt_planar.dim() != 4 or self.tgt_planar.shape[1] != 3:
+            raise ValueError("colour frames are [B,3,H,W], got %s" % (tuple(self.tgt_planar.shape),))
+        B, _, H, W = self.tgt_planar.shape
+        self.shape = (B, H, W)
+        dev = self.tgt_planar.device
+        self.tgt = torch.empty(B, H, W, 4, device=dev, dtype=torch.float32)
+        self.srcs = tuple(torch.empty(B, H, W, 4, device=dev, dtype=torch.float32) for _ in self.srcs_planar)
+        self.packed = False
+        if pack:
+            self.pack()
 
-    @staticmethod
-    def _pack(lib, img):
-        img = _f32c(img.detach())
-        B, C, H, W = img.shape
-        if C != 3:
-            raise ValueError("colour frames are [B,3,H,W], got %s" % (tuple(img.shape),))
-        out = torch.empty(B, H, W, 4, device=img.device, dtype=torch.float32)
-        native.check(lib.td_pack_rgbx(native.ptr(img), B, H, W, native.ptr(out), native.stream()), "td_pack_rgbx")
-        return out
+    def pack(self):
+        if not self.packed:
+            lib = native.load()
+            B, H, W = self.shape
+            for planar, out in zip((self.tgt_planar,) + self.srcs_planar, (self.tgt,) + self.srcs):
+                native.check(lib.td_pack_rgbx(native.ptr(planar), B, H, W, native.ptr(out), native.stream()), "td_pack_rgbx")
+            self.packed = True
+        return self
 
 
-def pack_frames(tgt, srcs):
-    return PackedFrames(tgt, srcs)
+def pack_frames(tgt, srcs, pack=True):
+    """``pack=False``: the RGBX copies are left to ``photo_identity`` (which writes them as a by-product)."""
+    return PackedFrames(tgt, srcs, pack)
 
 
 def _frames(tgt, srcs):
-    return tgt if isinstance(tgt, PackedFrames) else PackedFrames(tgt, srcs)
+    return tgt.pack() if isinstance(tgt, PackedFrames) else PackedFrames(tgt, srcs)
 
 
 def photo_identity(tgt, srcs=None):
     """Auto-mask identity term for every source frame, once per step.
     compute_reprojection_loss(inputs[("color", f, 0)], target) at
     mono/model/mono_fm_joint_inpaint/net.py:101-104 -> [B, n_src, H, W] (a view: the memory is [B,H,W,n_src], the layout
-    td_photo_fwd reads).  ``tgt``: the [B,3,H,W] target with ``srcs`` the list of sources, or a PackedFrames."""
+    td_photo_fwd reads).  ``tgt``: the [B,3,H,W] target with ``srcs`` the list of sources, or a PackedFrames -- whose RGBX copies
+    this call fills if they are not packed yet."""
     lib = native.load()
-    fr = _frames(tgt, srcs)
+    fr = tgt if isinstance(tgt, PackedFrames) else PackedFrames(tgt, srcs, pack=False)
     B, H, W = fr.shape
     out = torch.empty(B, H, W, len(fr.srcs), device=fr.tgt.device, dtype=torch.float32)
-    native.check(lib.td_photo_identity(native.ptr(fr.tgt), native.ptr_array(fr.srcs), len(fr.srcs), B, H, W,
-                                       native.ptr(out), native.stream()), "td_photo_identity")
+    emit = not fr.packed
+    native.check(lib.td_photo_identity(native.ptr(fr.tgt_planar), native.ptr_array(fr.srcs_planar), len(fr.srcs), B, H, W,
+                                       native.ptr(out), native.ptr(fr.tgt) if emit else None,
+                                       native.ptr_array(fr.srcs) if emit else None, native.stream()), "td_photo_identity")
+    fr.packed = True
     return out.permute(0, 3, 1, 2)
 
 
