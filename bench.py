@@ -188,7 +188,7 @@ def roofline_of_hot_kernels(cfg, batch):
                                           native.ptr(argmin), None, None, native.ptr(part), native.ptr(coef), st), "fwd")
 
         def bwd():
-            native.check(lib.td_photo_bwd(native.ptr(tgt_p), sp_p, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
+            native.check(lib.td_photo_bwd(native.ptr(tgt_p), sp_p, native.ptr(tgt), sp, n_src, native.ptr(disp), native.ptr(P), native.ptr(invK),
                                           native.ptr(argmin), native.ptr(coef), 1, native.ptr(gs), 1.0 / (px * 4), B, H, W, hs, ws,
                                           0.1, 100.0, native.ptr(d_up), native.ptr(dpp), st), "bwd")
 

@@ -114,9 +114,11 @@ int td_photo_fwd(const float* tgt, const float* const* src, int n_src,
  *   d_up      [n_src,B,H,W] (out, workspace): gradient w.r.t. the UPSAMPLED disparity, one plane per source frame
  *             (the frames of a column strip are separate wave tasks; their sum is the gradient)
  *   dP_partial[td_photo_bwd_num_blocks, n_src*12] (out): per-block partial sums of dL/dP
+ *   tgt, src  the NCHW frames [B,3,H,W]; tgt_rgbx, src_rgbx (both or neither NULL): their RGBX copies -- read instead of the
+ *             NCHW frames at the finest scale (2*hs >= H), where the disparity's detail breaks the coalescing of dword gathers
  * Follow with td_upsample_adjoint_planes (d_up planes -> d_disp) and td_reduce_dP.
  */
-int td_photo_bwd(const float* tgt, const float* const* src, int n_src,
+int td_photo_bwd(const float* tgt, const float* const* src, const float* tgt_rgbx, const float* const* src_rgbx, int n_src,
                  const float* disp, const float* P, const float* invK,
                  const uint8_t* argmin, const float* coef, int automask,
                  const float* gscale, float inv_count,

@@ -25,7 +25,7 @@ constexpr int BS_WAVES = 4;
 
 template <int NS>
 struct PhotoBwdArgs {
-  const float* tgt;
+  const float* tgt;          // NCHW frames, or RGBX pixels [B,H,W,4] in the PX form of the kernel
   const float* src[NS];
   const float* disp;
   const float* P;
@@ -42,7 +42,11 @@ struct PhotoBwdArgs {
   float min_disp, disp_range;
 };
 
-template <int NS>
+// PX: the frames are RGBX pixels (one 16-byte load per tap / target pixel instead of three dword loads).  Used at the FINEST scale
+// only (hs >= H/2): there the disparity carries per-pixel detail, the dword gathers of neighbouring lanes stop sharing cache lines
+// and the pixel-major form is 3 us faster (57.2 -> 54.5 us at B=12 192x640); at the coarser scales the warp is coherent, the
+// planar dword loads touch fewer lines and the pixel-major form is 1-3 us SLOWER (csrc/td_common.h, "packed frames").
+template <int NS, bool PX>
 // second bound: three waves per SIMD (<= 168 registers; the one-frame body takes 164 without spills)
 __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const PhotoBwdArgs<NS> a) {
   const int lane = threadIdx.x & 63;
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const Photo
   const int xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
   const float wl = (x == 1) ? 2.f : 1.f, wr = (x == W - 2) ? 2.f : 1.f;
 
-  const float* tgtb = a.tgt + (size_t)b * 3 * plane;
+  const float* tgtb = a.tgt + (size_t)b * (PX ? 4 : 3) * plane;
   const float* cfb = a.coef + (size_t)b * 9 * plane;
   const uint8_t* amb = a.argmin + (size_t)b * plane;
   float* dupb = a.d_up + ((size_t)f * a.B + b) * plane;      // this frame's plane of d_up [NS,B,H,W]
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const Photo
     const float* srcp = a.src[0];                    // (a select chain: dynamic indexing of the by-value argument struct would go to scratch)
 #pragma unroll
     for (int i = 1; i < NS; ++i) srcp = (f == i) ? a.src[i] : srcp;
-    const float* srcb = srcp + (size_t)b * 3 * plane;
+    const float* srcb = srcp + (size_t)b * (PX ? 4 : 3) * plane;
     float P[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) P[e] = a.P[(f * a.B + b) * 12 + e];
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const Photo
     float dv[4], dv_n[4], ul0, ul1, ul0_n, ul1_n;
     Tap tap = {};
     TapVals tv[3] = {};
+    TapVals4 tv4 = {};
     float depth_q = 0.f;
     // field pipeline, THREE rows deep (the backward is memory-latency bound: SQ_WAIT_ANY 47 % with two): slot A holds
     // coefficient row k (loaded two iterations ago), slot B row k+1 (loaded in the previous iteration); the raw arg-min
@@ -128,8 +133,13 @@ __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const Photo
       const int q = r - 1;
       const int qc = q < 0 ? 0 : (q > H - 1 ? H - 1 : q);
       const unsigned offq = (unsigned)(qc * W + xc);
+      if (PX) {
+        const f4 t = ld4_at(tgtb, offq * 16u);
+        yq3[0] = t[0]; yq3[1] = t[1]; yq3[2] = t[2];
+      } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) yq3[c] = ld_at(tgtb + (size_t)c * plane, offq * 4u);
+        for (int c = 0; c < 3; ++c) yq3[c] = ld_at(tgtb + (size_t)c * plane, offq * 4u);
+      }
       aq = amb[offq];
     };
     auto issue_warp = [&](int k, const float* d4, float l0, float l1) {
@@ -144,8 +154,12 @@ __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const Photo
         float pt[3], cz[3];
         tap = project_ray(rx0 + ik[1] * fy + ik[2], rx1 + ik[4] * fy + ik[5], rx2 + ik[7] * fy + ik[8], P, depth_q,
                           W, H, pt, cz);
+        if (PX) {
+          tv4 = load_taps4(srcb, W, tap);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tv[c] = load_taps(srcb + c * plane, W, tap);
+          for (int c = 0; c < 3; ++c) tv[c] = load_taps(srcb + c * plane, W, tap);
+        }
       }
     };
     issue_disp(y0 - 2, dv, ul0, ul1);                // q of k = 0
@@ -180,17 +194,18 @@ __global__ __launch_bounds__(BS_WAVES * 64, 3) void photo_bwd_kernel(const Photo
         const float mx = tap.gmx * sx_scale, my = tap.gmy * sy_scale;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+          const TapVals t = PX ? tap_channel(tv4, c) : tv[c];
           // weights re-formed here instead of carried across the row (4 registers); (float)x0 == floor(ix) after the
           // clamp, so these are the forward's ex * ey, ... bit for bit, summed in ATen's order nw, ne, sw, se
-          float o = tv[c].nw * (ex * ey);
-          o += tv[c].ne * (wx * ey);
-          o += tv[c].sw * (ex * wy);
-          o += tv[c].se * (wx * wy);
+          float o = t.nw * (ex * ey);
+          o += t.ne * (wx * ey);
+          o += t.sw * (ex * wy);
+          o += t.se * (wx * wy);
           xq[c] = o;
-          const float vnw = tv[c].nw;
-          const float vne = tap.in_e ? tv[c].ne : 0.f;
-          const float vsw = tap.in_s ? tv[c].sw : 0.f;
-          const float vse = (tap.in_e && tap.in_s) ? tv[c].se : 0.f;
+          const float vnw = t.nw;
+          const float vne = tap.in_e ? t.ne : 0.f;
+          const float vsw = tap.in_s ? t.sw : 0.f;
+          const float vse = (tap.in_e && tap.in_s) ? t.se : 0.f;
           dxi[c] = (-vnw * ey + vne * ey - vsw * wy + vse * wy) * mx;     // d x_c / d u
           dyi[c] = (-vnw * ex - vne * wx + vsw * ex + vse * wx) * my;     // d x_c / d v
         }
@@ -267,13 +282,14 @@ static int bwd_tasks(int B, int H, int W, int* nstrips, int* nchunks, int* rows)
 }
 
 template <int NS>
-static int run_bwd(const float* tgt, const float* const* src, const float* disp, const float* P,
+static int run_bwd(const float* tgt, const float* const* src, const float* tgt_px, const float* const* src_px, const float* disp, const float* P,
                    const float* invK, const uint8_t* argmin, const float* coef, int automask, const float* gscale,
                    float inv_count, int B, int H, int W, int hs, int ws, float min_depth,
                    float max_depth, float* d_up, float* dP_partial, hipStream_t st) {
   PhotoBwdArgs<NS> a;
-  a.tgt = tgt;
-  for (int i = 0; i < NS; ++i) a.src[i] = src[i];
+  const bool px = tgt_px != nullptr && src_px != nullptr && 2 * hs >= H;      // pixel-major frames at the finest scale only
+  a.tgt = px ? tgt_px : tgt;
+  for (int i = 0; i < NS; ++i) a.src[i] = px ? src_px[i] : src[i];
   a.disp = disp; a.P = P; a.invK = invK; a.argmin = argmin; a.coef = coef; a.gscale = gscale;
   a.d_up = d_up; a.dP_partial = dP_partial;
   a.B = B; a.H = H; a.W = W; a.hs = hs; a.ws = ws;
@@ -285,7 +301,10 @@ static int run_bwd(const float* tgt, const float* const* src, const float* disp,
   a.ntasks = bwd_tasks(B, H, W, &a.nstrips, &a.nchunks, &a.rows);
   const int blocks = (a.ntasks * NS + BS_WAVES - 1) / BS_WAVES;
   a.blocks_per_xcd = (blocks + 7) / 8;
-  hipLaunchKernelGGL((photo_bwd_kernel<NS>), dim3(a.blocks_per_xcd * 8), dim3(BS_WAVES * 64), 0, st, a);
+  if (px)
+    hipLaunchKernelGGL((photo_bwd_kernel<NS, true>), dim3(a.blocks_per_xcd * 8), dim3(BS_WAVES * 64), 0, st, a);
+  else
+    hipLaunchKernelGGL((photo_bwd_kernel<NS, false>), dim3(a.blocks_per_xcd * 8), dim3(BS_WAVES * 64), 0, st, a);
   return record_launch_error(hipGetLastError(), "td_photo_bwd");
 }
 
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(TD_THREADS) void upsample_adjoint_gather_kernel(
 
 }  // namespace td
 
-extern "C" int td_photo_bwd(const float* tgt, const float* const* src, int n_src, const float* disp,
+extern "C" int td_photo_bwd(const float* tgt, const float* const* src, const float* tgt_rgbx, const float* const* src_rgbx, int n_src, const float* disp,
                             const float* P, const float* invK, const uint8_t* argmin, const float* coef,
                             int automask, const float* gscale, float inv_count, int B, int H, int W, int hs, int ws,
                             float min_depth, float max_depth, float* d_up, float* dP_partial,
@@ -437,13 +456,15 @@ extern "C" int td_photo_bwd(const float* tgt, const float* const* src, int n_src
   if (n_src < 1 || n_src > TD_MAX_SRC || B <= 0 || hs <= 0 || ws <= 0 || hs > H || ws > W) return TD_ERR_BAD_ARG;
   if (!(min_depth > 0.f) || !(max_depth > min_depth)) return TD_ERR_BAD_ARG;
   for (int i = 0; i < n_src; ++i) if (!src[i]) return TD_ERR_BAD_ARG;
-  if (H < 3 || W < 3 || (long long)B * 3 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
+  if ((tgt_rgbx == nullptr) != (src_rgbx == nullptr)) return TD_ERR_BAD_ARG;
+  if (src_rgbx) for (int i = 0; i < n_src; ++i) if (!src_rgbx[i]) return TD_ERR_BAD_ARG;
+  if (H < 3 || W < 3 || (long long)B * 4 * H * W >= (1ll << 31)) return TD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   switch (n_src) {
-    case 1: return td::run_bwd<1>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
-    case 2: return td::run_bwd<2>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
-    case 3: return td::run_bwd<3>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
-    case 4: return td::run_bwd<4>(tgt, src, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 1: return td::run_bwd<1>(tgt, src, tgt_rgbx, src_rgbx, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 2: return td::run_bwd<2>(tgt, src, tgt_rgbx, src_rgbx, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 3: return td::run_bwd<3>(tgt, src, tgt_rgbx, src_rgbx, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
+    case 4: return td::run_bwd<4>(tgt, src, tgt_rgbx, src_rgbx, disp, P, invK, argmin, coef, automask, gscale, inv_count, B, H, W, hs, ws, min_depth, max_depth, d_up, dP_partial, st);
   }
   return TD_ERR_BAD_ARG;
 }

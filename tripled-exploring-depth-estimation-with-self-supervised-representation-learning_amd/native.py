@@ -32,7 +32,7 @@ SIGNATURES = {
     "td_photo_bwd_num_blocks": (_I, [_I, _I, _I]),
     "td_photo_identity": (_I, [_P, _PTRARR, _I, _I, _I, _I, _P, _P, _PTRARR, _P]),
     "td_photo_fwd": (_I, [_P, _PTRARR, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
-    "td_photo_bwd": (_I, [_P, _PTRARR, _I, _P, _P, _P, _P, _P, _I, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "td_photo_bwd": (_I, [_P, _PTRARR, _P, _PTRARR, _I, _P, _P, _P, _P, _P, _I, _P, _F, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "td_pack_rgbx": (_I, [_P, _I, _I, _I, _P, _P]),
     "td_upsample_adjoint": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "td_upsample_adjoint_planes": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -112,7 +112,7 @@ class _PhotometricScaleLoss(torch.autograd.Function):
                      "td_photo_fwd")
         inv_count = 1.0 / (float(B) * H * W * n_scales)
         native.check(lib.td_sum_scaled(native.ptr(partial), nblk, inv_count, native.ptr(loss), st), "td_sum_scaled")
-        ctx.save_for_backward(disp, P, tgt_planar, invK, argmin, coef if coef is not None else argmin, *srcs_planar)
+        ctx.save_for_backward(disp, P, tgt_planar, invK, argmin, coef if coef is not None else argmin, tgt, *srcs_planar, *srcs)
         ctx.meta = (min_depth, max_depth, inv_count, idloss is not None, n_src)
         ctx.mark_non_differentiable(argmin)
         if keep_warped:
@@ -123,8 +123,9 @@ class _PhotometricScaleLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_argmin, _g_warped):
         lib = native.load()
-        disp, P, tgt, invK, argmin, coef, *srcs = ctx.saved_tensors
+        disp, P, tgt, invK, argmin, coef, tgt_x, *both = ctx.saved_tensors
         min_depth, max_depth, inv_count, automask, n_src = ctx.meta
+        srcs, srcs_x = both[:n_src], both[n_src:]      # NCHW frames, and their RGBX copies (read at the finest scale)
         B, _, H, W = tgt.shape                     # NCHW frames
         hs, ws = disp.shape[2], disp.shape[3]
         dev = tgt.device
@@ -133,7 +134,8 @@ class _PhotometricScaleLoss(torch.autograd.Function):
         nblk = lib.td_photo_bwd_num_blocks(B, H, W)
         dP_part = torch.empty(nblk, n_src * 12, device=dev, dtype=torch.float32)
         st = native.stream()
-        native.check(lib.td_photo_bwd(native.ptr(tgt), native.ptr_array(srcs), n_src, native.ptr(disp),
+        native.check(lib.td_photo_bwd(native.ptr(tgt), native.ptr_array(srcs), native.ptr(tgt_x), native.ptr_array(srcs_x), n_src,
+                                      native.ptr(disp),
                                       native.ptr(P), native.ptr(invK), native.ptr(argmin), native.ptr(coef),
                                       int(automask), native.ptr(g), inv_count, B, H, W, hs, ws, float(min_depth),
                                       float(max_depth), native.ptr(d_up), native.ptr(dP_part), st),
