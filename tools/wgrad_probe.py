@@ -28,8 +28,12 @@ def timeit(fn, iters=20):
 
 def main():
     torch.backends.cudnn.benchmark = True
-    tot = [0.0, 0.0, 0.0, 0.0]
-    print("%-24s %10s %10s %10s %10s" % ("B,H,W,K,N", "aten both", "aten dgrad", "mm dgrad", "mm wgrad"))
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native
+    from tripled_amd.ops import _raw
+    lib = native.load()
+    tot = [0.0, 0.0, 0.0, 0.0, 0.0]
+    print("%-24s %10s %10s %10s %10s %10s" % ("B,H,W,K,N", "aten both", "aten dgrad", "mm dgrad", "mm wgrad", "td wgrad"))
     for B, H, W, K, N in SHAPES:
         x = torch.randn(B, K, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(N, K, 1, 1, device="cuda") / K ** 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -51,11 +55,18 @@ def main():
         def mm_w():
             torch.mm(dy2.t(), x2)
 
-        t = [timeit(both), timeit(dgrad), timeit(mm_d), timeit(mm_w)]
-        for i in range(4):
+        dw = torch.empty_like(w)
+        ws = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), device="cuda")
+        st = native.stream()
+
+        def td_w():      # the hand-written kernel + its ordered slab sum (csrc/td_conv1x1.hip)
+            native.check(lib.td_conv1x1_wgrad(_raw(dy), _raw(x), M, K, N, H, W, 1, native.DTYPE_CODES[dw.dtype], _raw(dw), native.ptr(ws), st), "wgrad")
+
+        t = [timeit(both), timeit(dgrad), timeit(mm_d), timeit(mm_w), timeit(td_w)]
+        for i in range(5):
             tot[i] += t[i]
-        print("%-24s %10.1f %10.1f %10.1f %10.1f" % (",".join(map(str, (B, H, W, K, N))), *t))
-    print("%-24s %10.1f %10.1f %10.1f %10.1f   (us, sum)" % ("sum", *tot))
+        print("%-24s %10.1f %10.1f %10.1f %10.1f %10.1f" % (",".join(map(str, (B, H, W, K, N))), *t))
+    print("%-24s %10.1f %10.1f %10.1f %10.1f %10.1f   (us, sum)" % ("sum", *tot))
 
 
 if __name__ == "__main__":

@@ -235,24 +235,123 @@ __global__ __launch_bounds__(64) void bn_coef_from_sums_kernel(const float* __re
   dbeta[c] = db_tot;
 }
 
-template <typename T>
+// ---------------------------------------------------------------------------------------------
+// Finalize inside the consumer.  A finalize launch is 3-8 us of latency for a few KB of sums and there are ~300 of them in a
+// training step; when a statistics group has at most BN_PRO_MAX_S partial rows (every layer of the two deepest ResNet stages)
+// each 64-channel block of bn_apply / bn_dx re-reduces the partials of ITS channels in its prologue instead: S x 64 float2,
+// all loads issued at once, the same ordered sum in every block, so all blocks of a launch normalise with bit-identical
+// statistics.  The blocks with blockIdx.y == 0 write save_mean / save_invstd (dgamma / dbeta), block (y, z) == (0, 0) updates
+// the running statistics group by group.  Larger S keeps the separate 16-channel finalize kernels above.
+// ---------------------------------------------------------------------------------------------
+constexpr int BN_PRO_MAX_S = 96;
+constexpr int BN_PRO_PARTS = BN_THREADS / 64;
+constexpr int BN_PRO_DEPTH = BN_PRO_MAX_S / BN_PRO_PARTS;
+// (A, B) = sums over the S partial rows for channel 64 * ct + threadIdx.x, valid in threads 0..63; block-uniform call
+__device__ __forceinline__ void bn_tile_sums(const float* __restrict__ ws, int S, int C, int ct, float& A, float& B) {
+  __shared__ float red[2][BN_PRO_PARTS][64];
+  const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
+  const float* p = ws + ((size_t)ct * 64 + c) * 2;
+  float2 v[BN_PRO_DEPTH];
+#pragma unroll
+  for (int u = 0; u < BN_PRO_DEPTH; ++u) {
+    const int row = part + BN_PRO_PARTS * u;
+    v[u] = *reinterpret_cast<const float2*>(p + (size_t)(row < S ? row : 0) * C * 2);
+  }
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int u = 0; u < BN_PRO_DEPTH; ++u) {
+    const bool ok = part + BN_PRO_PARTS * u < S;
+    a += ok ? v[u].x : 0.f;
+    b += ok ? v[u].y : 0.f;
+  }
+  red[0][part][c] = a;
+  red[1][part][c] = b;
+  __syncthreads();
+  A = 0.f;
+  B = 0.f;
+  if (tid < 64) {
+#pragma unroll
+    for (int j = 0; j < BN_PRO_PARTS; ++j) { A += red[0][j][c]; B += red[1][j][c]; }
+  }
+  __syncthreads();      // red is reused by the next call
+}
+
+struct BnFinFwd {       // forward statistics formed in bn_apply's prologue (FIN = true)
+  const float* ws;      // [G, S, C, 2] partial (sum x, sum x^2)
+  int S, G;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+};
+struct BnFinBwd {       // backward coefficients formed in bn_dx's prologue (FIN = true)
+  const float* ws;      // [G, S, C, 2] partial (sum g, sum g (x - mean))
+  int S, G;
+  float* dgamma;
+  float* dbeta;
+};
+
+template <typename T, bool FIN = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                              long long M, int C, int rows_per_split, int relu, T* __restrict__ y) {
+                                                              long long M, int C, int rows_per_split, int relu, T* __restrict__ y,
+                                                              BnFinFwd fin) {
   const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
   const int grp = blockIdx.z;
   const long long base = (long long)grp * M;
   const long long r0 = base + (long long)blockIdx.y * rows_per_split;
   const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
-  mean += (size_t)grp * C;
-  invstd += (size_t)grp * C;
   float sc[8], sh[8];
+  if constexpr (FIN) {
+    __shared__ float s_sc[64], s_sh[64];
+    const int c = blockIdx.x * 64 + (tid & 63);
+    float A, B;
+    bn_tile_sums(fin.ws + (size_t)grp * fin.S * C * 2, fin.S, C, blockIdx.x, A, B);
+    if (tid < 64) {
+      const double m = (double)A / (double)M;
+      double var = (double)B / (double)M - m * m;      // biased variance, formed in double
+      var = var > 0.0 ? var : 0.0;
+      const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)fin.eps));
+      const float scv = gamma[c] * isf;
+      s_sc[tid] = scv;
+      s_sh[tid] = beta[c] - mf * scv;
+      if (blockIdx.y == 0) {
+        fin.save_mean[(size_t)grp * C + c] = mf;
+        fin.save_invstd[(size_t)grp * C + c] = isf;
+      }
+    }
+    if (fin.running_mean && blockIdx.y == 0 && blockIdx.z == 0) {
+      // groups in order: one momentum update per group, exactly like G separate calls
+      double rm = 0.0, rv = 0.0;
+      if (tid < 64) { rm = fin.running_mean[c]; rv = fin.running_var[c]; }
+      for (int g2 = 0; g2 < fin.G; ++g2) {
+        float A2 = A, B2 = B;
+        if (g2 != 0) bn_tile_sums(fin.ws + (size_t)g2 * fin.S * C * 2, fin.S, C, blockIdx.x, A2, B2);
+        if (tid < 64) {
+          const double m = (double)A2 / (double)M;
+          double var = (double)B2 / (double)M - m * m;
+          var = var > 0.0 ? var : 0.0;
+          const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+          rm = (double)(float)((1.0 - fin.momentum) * rm + fin.momentum * m);
+          rv = (double)(float)((1.0 - fin.momentum) * rv + fin.momentum * unbiased);
+        }
+      }
+      if (tid < 64) { fin.running_mean[c] = (float)rm; fin.running_var[c] = (float)rv; }
+    }
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    sc[i] = gamma[col + i] * invstd[col + i];
-    sh[i] = beta[col + i] - mean[col + i] * sc[i];
+    for (int i = 0; i < 8; ++i) { sc[i] = s_sc[cx * 8 + i]; sh[i] = s_sh[cx * 8 + i]; }
+  } else {
+    mean += (size_t)grp * C;
+    invstd += (size_t)grp * C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = gamma[col + i] * invstd[col + i];
+      sh[i] = beta[col + i] - mean[col + i] * sc[i];
+    }
   }
   for (long long r = r0 + ry; r < r1; r += BN_UNROLL * BN_RY) {
     float vx[BN_UNROLL][8], vr[BN_UNROLL][8];
@@ -313,28 +412,61 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_bwd_kernel(const f
   }
 }
 
-template <typename T>
+template <typename T, bool FIN = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ coef, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, long long M, int C, int rows_per_split,
-                                                           int relu, T* __restrict__ dx, T* __restrict__ dres) {
+                                                           int relu, T* __restrict__ dx, T* __restrict__ dres, BnFinBwd fin) {
   const int tid = threadIdx.x, cx = tid & 7, ry = tid >> 3;
   const int grp = blockIdx.z;
   const long long base = (long long)grp * M;
   const long long r0 = base + (long long)blockIdx.y * rows_per_split;
   const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
-  coef += (size_t)grp * C * 3;
+  float k0[8], k1[8], k2[8];
+  if constexpr (FIN) {
+    // dgamma, dbeta (summed over the statistics groups) and this group's dx coefficients  dx = k0 * g + k1 * x + k2
+    __shared__ float s_k[3][64];
+    const int c = blockIdx.x * 64 + (tid & 63);
+    const float inv_m = 1.f / (float)M;
+    float A, B;
+    bn_tile_sums(fin.ws + (size_t)grp * fin.S * C * 2, fin.S, C, blockIdx.x, A, B);
+    if (tid < 64) {
+      const float is = invstd[(size_t)grp * C + c], mu = mean[(size_t)grp * C + c];
+      const float dg = B * is;                     // sum g * xhat
+      const float c0 = gamma[c] * is;
+      const float c1 = -c0 * is * dg * inv_m;      // multiplies (x - mean)
+      s_k[0][tid] = c0;
+      s_k[1][tid] = c1;
+      s_k[2][tid] = -c0 * A * inv_m - c1 * mu;
+    }
+    if (blockIdx.y == 0 && blockIdx.z == 0) {
+      float dg_tot = 0.f, db_tot = 0.f;
+      for (int g2 = 0; g2 < fin.G; ++g2) {
+        float A2 = A, B2 = B;
+        if (g2 != 0) bn_tile_sums(fin.ws + (size_t)g2 * fin.S * C * 2, fin.S, C, blockIdx.x, A2, B2);
+        if (tid < 64) {
+          dg_tot += B2 * invstd[(size_t)g2 * C + c];
+          db_tot += A2;
+        }
+      }
+      if (tid < 64) { fin.dgamma[c] = dg_tot; fin.dbeta[c] = db_tot; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { k0[i] = s_k[0][cx * 8 + i]; k1[i] = s_k[1][cx * 8 + i]; k2[i] = s_k[2][cx * 8 + i]; }
+  } else {
+    coef += (size_t)grp * C * 3;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      k0[i] = coef[(col + i) * 3 + 0];
+      k1[i] = coef[(col + i) * 3 + 1];
+      k2[i] = coef[(col + i) * 3 + 2];
+    }
+  }
   mean += (size_t)grp * C;
   invstd += (size_t)grp * C;
-  float k0[8], k1[8], k2[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    k0[i] = coef[(col + i) * 3 + 0];
-    k1[i] = coef[(col + i) * 3 + 1];
-    k2[i] = coef[(col + i) * 3 + 2];
-  }
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { sc[i] = 0.f; sh[i] = 0.f; }
@@ -390,6 +522,26 @@ static inline int bn_rows_per_split(long long M, int S) {
   return (int)((r + BN_RY - 1) / BN_RY * BN_RY);
 }
 
+// finalize (own launch, or in the apply kernel's prologue when the partial rows are few) + apply, from partial sums
+template <typename T>
+static void launch_bn_finalize_apply(const void* x, const void* res, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                     float momentum, float eps, int relu, long long Mg, int G, int C, const float* partials, int S, void* y,
+                                     float* save_mean, float* save_invstd, hipStream_t st) {
+  const bool pro = S <= BN_PRO_MAX_S;
+  const int S2 = bn_splits(Mg, C, (pro ? 1024 : 2048) / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
+  if (pro) {
+    const BnFinFwd fin = {partials, S, G, eps, momentum, rmean, rvar, save_mean, save_invstd};
+    hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
+                       (const float*)nullptr, (const float*)nullptr, Mg, C, rps2, relu, (T*)y, fin);
+    return;
+  }
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, partials, S, C, Mg, G, eps, momentum, rmean, rvar,
+                     save_mean, save_invstd);
+  hipLaunchKernelGGL((bn_apply_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
+                     (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y, BnFinFwd{});
+}
+
 template <typename T>
 static int run_bn_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* rmean, float* rvar,
                       float momentum, float eps, int relu, long long M, int G, int C, void* y, float* save_mean, float* save_invstd,
@@ -399,11 +551,7 @@ static int run_bn_fwd(const void* x, const void* res, const float* gamma, const 
   const int S_eff = (int)((Mg + rps - 1) / rps);
   hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
                      (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C, rps, 0, ws);
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, eps, momentum,
-                     rmean, rvar, save_mean, save_invstd);
-  const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)x,
-                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y);
+  launch_bn_finalize_apply<T>(x, res, gamma, beta, rmean, rvar, momentum, eps, relu, Mg, G, C, ws, S_eff, y, save_mean, save_invstd, st);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
@@ -416,11 +564,19 @@ static int run_bn_bwd(const void* dy, const void* x, const void* y, const float*
   float* coef = ws + (size_t)2 * S_eff * C * G;
   hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                      (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, gamma, mean,
-                     invstd, dgamma, dbeta, coef);
-  const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
-  hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)dy,
-                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres);
+  const bool pro = S_eff <= BN_PRO_MAX_S;
+  const int S2 = bn_splits(Mg, C, (pro ? 1024 : 2048) / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
+  if (pro) {
+    const BnFinBwd fin = {ws, S_eff, G, dgamma, dbeta};
+    hipLaunchKernelGGL((bn_dx_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)nullptr,
+                       mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, fin);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, gamma, mean,
+                       invstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL((bn_dx_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)coef,
+                       mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, BnFinBwd{});
+  }
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
@@ -451,8 +607,8 @@ static int run_bn_sync_apply(const void* x, const void* res, const float* sums, 
   hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3(C / 64), dim3(64), 0, st, sums, count, C, G, eps, momentum, rmean, rvar, save_mean,
                      save_invstd);
   const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)x,
-                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y);
+  hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)x,
+                     (const T*)res, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y, BnFinFwd{});
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
@@ -464,8 +620,8 @@ static int run_bn_sync_dx(const void* dy, const void* x, const void* y, const fl
   hipLaunchKernelGGL(bn_coef_from_sums_kernel, dim3(C / 64), dim3(64), 0, st, local, global, count, C, G, gamma, mean, invstd, dgamma, dbeta,
                      coef);
   const int S2 = bn_splits(Mg, C, 2048 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
-  hipLaunchKernelGGL((bn_dx_kernel<T>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)dy,
-                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres);
+  hipLaunchKernelGGL((bn_dx_kernel<T, false>), dim3(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G), dim3(BN_THREADS), 0, st, (const T*)dy,
+                     (const T*)x, (const T*)y, (const float*)coef, mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, BnFinBwd{});
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
@@ -512,8 +668,8 @@ extern "C" int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype
   return TD_ERR_UNSUPPORTED;
 }
 
-// Forward with the partial sums already formed by the producing kernel (td_conv1x1_fwd's epilogue): finalize + apply,
-// two launches instead of three and no statistics pass over x.  partials: [groups, stat_rows, C, 2] f32.
+// Forward with the partial sums already formed by the producing kernel (td_conv1x1_fwd's epilogue): finalize + apply (one
+// launch when stat_rows <= 96, else two) and no statistics pass over x.  partials: [groups, stat_rows, C, 2] f32.
 extern "C" int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
                                        float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
                                        int groups, int C, const float* partials, int stat_rows, void* y, float* save_mean,
@@ -525,17 +681,12 @@ extern "C" int td_bn_fwd_from_partials(const void* x, const void* residual, int 
   if (dtype != TD_DTYPE_BF16 && dtype != TD_DTYPE_F32) return TD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const long long Mg = M / groups;
-  hipLaunchKernelGGL(td::bn_finalize_fwd_kernel, dim3(C / td::BN_FIN_CH), dim3(td::BN_FIN_THREADS), 0, st, partials, stat_rows, C, Mg, groups, eps,
-                     momentum, running_mean, running_var, save_mean, save_invstd);
-  const int S2 = td::bn_splits(Mg, C, 2048 / groups, 4096), rps2 = td::bn_rows_per_split(Mg, S2);
-  const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), groups);
   if (dtype == TD_DTYPE_BF16)
-    hipLaunchKernelGGL((td::bn_apply_kernel<__hip_bfloat16>), grid, dim3(td::BN_THREADS), 0, st, (const __hip_bfloat16*)x,
-                       (const __hip_bfloat16*)residual, gamma, beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2,
-                       relu, (__hip_bfloat16*)y);
+    td::launch_bn_finalize_apply<__hip_bfloat16>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, Mg, groups, C, partials,
+                                                 stat_rows, y, save_mean, save_invstd, st);
   else
-    hipLaunchKernelGGL((td::bn_apply_kernel<float>), grid, dim3(td::BN_THREADS), 0, st, (const float*)x, (const float*)residual, gamma,
-                       beta, (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (float*)y);
+    td::launch_bn_finalize_apply<float>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, Mg, groups, C, partials, stat_rows,
+                                        y, save_mean, save_invstd, st);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 

@@ -161,46 +161,58 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_kernel(
   const long long m_hi = (m_lo + rows_per_split < M) ? m_lo + rows_per_split : M;
   const int nstage = (int)((m_hi - m_lo + WG_T - 1) / WG_T);
 
-  // staging: thread t moves 16-byte chunk (t & 7) of rows (t >> 3) and (t >> 3) + 32 of both tiles
+  // staging: thread t moves 16-byte chunk (t & 7) of rows (t >> 3) and (t >> 3) + 32 of both tiles.  A stage is four MFMAs per
+  // wave (~0.15 us) against a global-load round trip of 1-2 us and a workgroup has only a handful of stages, so the loads run
+  // TWO stages ahead of the arithmetic: two register sets (a: even stages, b: odd stages), each written to its LDS buffer one
+  // iteration after it was requested (one stage ahead left the kernel waiting on memory at 21 us per layer).
   const int lc = tid & 7, lr = tid >> 3;
-  uint4 ry0, ry1, rx0, rx1;
-#define WG_LOAD(st)                                                                                             \
-  {                                                                                                             \
-    const long long r0 = m_lo + (long long)(st) * WG_T + lr, r1 = r0 + 32;                                      \
-    const uint4 z = make_uint4(0, 0, 0, 0);                                                                     \
-    ry0 = r0 < m_hi ? *reinterpret_cast<const uint4*>(dy + r0 * N + n0 + lc * 8) : z;                           \
-    ry1 = r1 < m_hi ? *reinterpret_cast<const uint4*>(dy + r1 * N + n0 + lc * 8) : z;                           \
-    rx0 = r0 < m_hi ? *reinterpret_cast<const uint4*>(x + cv_src_row(r0, geom) * (long long)K + k0 + lc * 8) : z; \
-    rx1 = r1 < m_hi ? *reinterpret_cast<const uint4*>(x + cv_src_row(r1, geom) * (long long)K + k0 + lc * 8) : z; \
+  uint4 ry0a, ry1a, rx0a, rx1a, ry0b, ry1b, rx0b, rx1b;
+#define WG_LOAD(st, S)                                                                                             \
+  {                                                                                                                \
+    const long long r0 = m_lo + (long long)(st) * WG_T + lr, r1 = r0 + 32;                                         \
+    const uint4 z = make_uint4(0, 0, 0, 0);                                                                        \
+    ry0##S = r0 < m_hi ? *reinterpret_cast<const uint4*>(dy + r0 * N + n0 + lc * 8) : z;                           \
+    ry1##S = r1 < m_hi ? *reinterpret_cast<const uint4*>(dy + r1 * N + n0 + lc * 8) : z;                           \
+    rx0##S = r0 < m_hi ? *reinterpret_cast<const uint4*>(x + cv_src_row(r0, geom) * (long long)K + k0 + lc * 8) : z; \
+    rx1##S = r1 < m_hi ? *reinterpret_cast<const uint4*>(x + cv_src_row(r1, geom) * (long long)K + k0 + lc * 8) : z; \
   }
-#define WG_WRITE(buf)                                                                            \
+#define WG_WRITE(buf, S)                                                                         \
   {                                                                                              \
     unsigned char* b_ = lds + (buf) * STAGE;                                                     \
-    *reinterpret_cast<uint4*>(b_ + lr * WG_PITCH + lc * 16) = ry0;                               \
-    *reinterpret_cast<uint4*>(b_ + (lr + 32) * WG_PITCH + lc * 16) = ry1;                        \
-    *reinterpret_cast<uint4*>(b_ + TILE_BYTES + lr * WG_PITCH + lc * 16) = rx0;                  \
-    *reinterpret_cast<uint4*>(b_ + TILE_BYTES + (lr + 32) * WG_PITCH + lc * 16) = rx1;           \
+    *reinterpret_cast<uint4*>(b_ + lr * WG_PITCH + lc * 16) = ry0##S;                            \
+    *reinterpret_cast<uint4*>(b_ + (lr + 32) * WG_PITCH + lc * 16) = ry1##S;                     \
+    *reinterpret_cast<uint4*>(b_ + TILE_BYTES + lr * WG_PITCH + lc * 16) = rx0##S;               \
+    *reinterpret_cast<uint4*>(b_ + TILE_BYTES + (lr + 32) * WG_PITCH + lc * 16) = rx1##S;        \
+  }
+#define WG_MFMA(buf)                                                                             \
+  {                                                                                              \
+    const unsigned char* ty = lds + (buf) * STAGE;                                               \
+    const unsigned char* tx = ty + TILE_BYTES;                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < WG_T / 16; ++ks) {                                   \
+      const cv_bf16x8 fa = wg_frag(ty, wn * 32, ks, lane); /* A[i = n][r = m] */                 \
+      const cv_bf16x8 fb = wg_frag(tx, wk * 32, ks, lane); /* B[r = m][j = k] */                 \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);                       \
+    }                                                                                            \
   }
   cv_f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  WG_LOAD(0)
-  WG_WRITE(0)
+  WG_LOAD(0, a)
+  if (nstage > 1) WG_LOAD(1, b)
+  WG_WRITE(0, a)
   __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const bool more = st + 1 < nstage;
-    if (more) WG_LOAD(st + 1)
-    const unsigned char* ty = lds + (st & 1) * STAGE;
-    const unsigned char* tx = ty + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < WG_T / 16; ++ks) {
-      const cv_bf16x8 fa = wg_frag(ty, wn * 32, ks, lane);      // A[i = n][r = m]
-      const cv_bf16x8 fb = wg_frag(tx, wk * 32, ks, lane);      // B[r = m][j = k]
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
-    }
-    if (more) WG_WRITE((st + 1) & 1)
+  for (int st = 0; st < nstage; st += 2) {
+    if (st + 2 < nstage) WG_LOAD(st + 2, a)
+    WG_MFMA(0)
+    if (st + 1 < nstage) WG_WRITE(1, b)
+    __syncthreads();
+    if (st + 1 >= nstage) break;
+    if (st + 3 < nstage) WG_LOAD(st + 3, b)
+    WG_MFMA(1)
+    if (st + 2 < nstage) WG_WRITE(0, a)
     __syncthreads();
   }
+#undef WG_MFMA
 #undef WG_LOAD
 #undef WG_WRITE
   // D[i = n][j = k]: lane -> k = k0 + 32 wk + (lane & 31), register r -> n = n0 + 32 wn + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)

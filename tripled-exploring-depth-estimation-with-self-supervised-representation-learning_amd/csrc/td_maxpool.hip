@@ -5,110 +5,12 @@
 // Tie-break and NaN handling follow ATen's max_pool2d: row-major scan, strict '>', NaN wins.
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+
 #include "td_common.h"
 #include "td_vec8.h"
 
 namespace td {
-
-// one thread = one output pixel x 8 consecutive channels
-template <typename T>
-__global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_kernel(const T* __restrict__ in, int N, int H, int W, int C,
-                                                                  T* __restrict__ out, uint8_t* __restrict__ idx) {
-  const int c8 = C >> 3;
-  const long long gid = (long long)blockIdx.x * TD_THREADS + threadIdx.x;
-  const long long total = (long long)N * H * W * c8;
-  if (gid >= total) return;
-  const int cv = (int)(gid % c8);
-  const long long pix = gid / c8;
-  const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
-  float best[8];
-  unsigned char arg[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = 12; }
-  const T* base = in + (size_t)n * H * W * C + (size_t)cv * 8;
-#pragma unroll
-  for (int dy = 0; dy < 5; ++dy) {
-    const int yy = y + dy - 2;
-    if (yy < 0 || yy >= H) continue;
-#pragma unroll
-    for (int dx = 0; dx < 5; ++dx) {
-      const int xx = x + dx - 2;
-      if (xx < 0 || xx >= W) continue;
-      float v[8];
-      load8(base + ((size_t)yy * W + xx) * C, v);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; arg[i] = (unsigned char)(dy * 5 + dx); }
-      }
-    }
-  }
-  const size_t o = ((size_t)pix) * C + (size_t)cv * 8;
-  store8(out + o, best);
-  uint2 packed;
-  packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
-  packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
-  *reinterpret_cast<uint2*>(idx + o) = packed;
-}
-
-// LDS-tiled forward.  The one-output-per-thread form above reads every input vector 25 times through L1/L2 (1.2 GB of
-// cache traffic for the 47 MB map of the last decoder stage: 200 us, 0.6 TB/s of useful bytes); here a block stages an
-// (8+4) x (16+4) pixel tile of a 64-channel slab in LDS once (1.9x the tile's bytes from global memory, 30 KB) and the 25
-// window reads come from LDS with conflict-free 16-byte accesses (consecutive threads = consecutive channel vectors).
-// Same scan order and tie-break as above; positions outside the image hold -inf and can never be selected.
-constexpr int MP_TH = 8, MP_TW = 16, MP_CV = 8;      // tile rows, tile columns, 8-channel vectors per slab (64 channels)
-template <typename T>
-__global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_lds_kernel(const T* __restrict__ in, int N, int H, int W, int C,
-                                                                      T* __restrict__ out, uint8_t* __restrict__ idx) {
-  struct alignas(16) Vec { T v[8]; };
-  __shared__ Vec tile[MP_TH + 4][MP_TW + 4][MP_CV];
-  const int slabs = C / (8 * MP_CV);
-  const int n = blockIdx.z / slabs, slab = blockIdx.z % slabs;
-  const int ty0 = blockIdx.y * MP_TH, tx0 = blockIdx.x * MP_TW;
-  const T* base = in + (size_t)n * H * W * C + (size_t)slab * (8 * MP_CV);
-  // stage the tile + 2-pixel halo: consecutive threads take consecutive channel vectors of a pixel (128 contiguous bytes)
-  for (int e = threadIdx.x; e < (MP_TH + 4) * (MP_TW + 4) * MP_CV; e += TD_THREADS) {
-    const int cv = e % MP_CV, p = e / MP_CV;
-    const int px = p % (MP_TW + 4), py = p / (MP_TW + 4);
-    const int yy = ty0 + py - 2, xx = tx0 + px - 2;
-    Vec val;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      val = *reinterpret_cast<const Vec*>(base + ((size_t)yy * W + xx) * C + (size_t)cv * 8);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) val.v[i] = T(-INFINITY);
-    }
-    tile[py][px][cv] = val;
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < MP_TH * MP_TW * MP_CV; o += TD_THREADS) {
-    const int cv = o % MP_CV, p = o / MP_CV;
-    const int lx = p % MP_TW, ly = p / MP_TW;
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (y >= H || x >= W) continue;
-    float best[8];
-    unsigned char arg[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = 12; }
-#pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        float v[8];
-        load8(tile[ly + dy][lx + dx][cv].v, v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; arg[i] = (unsigned char)(dy * 5 + dx); }
-        }
-      }
-    }
-    const size_t off = (((size_t)n * H + y) * W + x) * C + (size_t)slab * (8 * MP_CV) + (size_t)cv * 8;
-    store8(out + off, best);
-    uint2 packed;
-    packed.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24);
-    packed.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24);
-    *reinterpret_cast<uint2*>(idx + off) = packed;
-  }
-}
 
 // one thread = one input pixel x 8 channels: sum the gradients of the outputs that selected it
 template <typename T>
@@ -151,6 +53,254 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __res
     }
   }
   store8(gin + (size_t)pix * C + (size_t)cv * 8, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column-march forms.  The kernels above are latency chains: the LDS tile is staged by 7-8 dependent global loads per thread
+// and the gather backward takes its 25 gradient loads under divergent branches, one L2 round trip after the other
+// (163 / 136 us on the 47 MB map of the finest CRP stage: 0.7 TB/s of the 118 MB each has to move).  Here one thread owns a
+// pixel column x 8 channels of a strip of rows and walks down it: every row costs 5 unconditional 16-byte loads (x-2..x+2, the
+// horizontal neighbours come out of L1), the next row's loads are issued before this row's arithmetic, and the vertical
+// window lives in a 5-deep register ring -- no LDS, no barrier, no branch on data.
+//   forward : row maximum + its first column (ATen's scan order is row-major, so "first maximum" = first row holding the
+//             maximum, first column inside that row; "NaN wins" = last NaN = last row holding one, last NaN inside it: the
+//             two-stage scan below keeps both rules), then the same scan down the 5 ring rows;
+//   backward: output row r adds into the ring slot of input row r + dy - 2 where its recorded offset says (dy, dx) and dx
+//             matches the column it was loaded from; the slot of input row r - 2 is complete after row r and is written.
+// Rows/columns outside the map load a clamped address and are replaced by -inf / "no offset".
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<__hip_bfloat16> {
+  unsigned w[4];
+  __device__ __forceinline__ void load(const __hip_bfloat16* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w;
+  }
+  __device__ __forceinline__ void neg_inf_unless(bool ok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = ok ? w[i] : 0xff80ff80u;
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <>
+struct Raw8<float> {
+  float w[8];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  }
+  __device__ __forceinline__ void neg_inf_unless(bool ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = ok ? w[i] : -INFINITY;
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = w[i];
+  }
+};
+
+struct MarchCoord {
+  int cv, x, n, y0, y1;
+  bool live;
+};
+// thread -> (image, strip of TH rows, column, 8-channel vector); channel vectors fastest: a wave reads whole pixels
+__device__ __forceinline__ MarchCoord march_coord(int N, int H, int W, int C, int TH, int strips) {
+  MarchCoord m;
+  const int c8 = C >> 3;
+  const long long gid = (long long)blockIdx.x * TD_THREADS + threadIdx.x;
+  m.live = gid < (long long)N * strips * W * c8;
+  long long t = m.live ? gid : 0;
+  m.cv = (int)(t % c8); t /= c8;
+  m.x = (int)(t % W); t /= W;
+  const int strip = (int)(t % strips);
+  m.n = (int)(t / strips);
+  m.y0 = strip * TH;
+  m.y1 = m.y0 + TH < H ? m.y0 + TH : H;
+  return m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_march_kernel(const T* __restrict__ in, int N, int H, int W, int C, int TH,
+                                                                        int strips, T* __restrict__ out, uint8_t* __restrict__ idx) {
+  const MarchCoord m = march_coord(N, H, W, C, TH, strips);
+  if (!m.live) return;
+  const T* base = in + (size_t)m.n * H * W * C + (size_t)m.cv * 8;
+  bool okx[5];
+  size_t xo[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int xx = m.x + k - 2;
+    okx[k] = xx >= 0 && xx < W;
+    xo[k] = (size_t)(okx[k] ? xx : m.x) * C;
+  }
+  float hm[5][8];        // ring of row maxima, slot = (row - first row) % 5
+  unsigned hd[5];        // their columns, 4 bits per channel
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    hd[s] = 0x22222222u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hm[s][i] = -INFINITY;
+  }
+  const int rstart = m.y0 - 2, rend = m.y1 + 1;
+  Raw8<T> cur[5], nxt[5];
+  {
+    const int rc = rstart < 0 ? 0 : rstart;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) cur[k].load(base + (size_t)rc * W * C + xo[k]);
+  }
+  for (int rbase = rstart; rbase <= rend; rbase += 5) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int r = rbase + j;
+      if (r <= rend) {
+        {   // next row's loads first
+          int rn = r + 1;
+          rn = rn < 0 ? 0 : (rn >= H ? H - 1 : rn);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) nxt[k].load(base + (size_t)rn * W * C + xo[k]);
+        }
+        const bool oky = r >= 0 && r < H;
+        float best[8];
+        unsigned col = 0x22222222u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) best[i] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          cur[k].neg_inf_unless(oky && okx[k]);
+          float v[8];
+          cur[k].unpack(v);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool take = (v[i] > best[i]) | (v[i] != v[i]);
+            best[i] = take ? v[i] : best[i];
+            col = take ? ((col & ~(0xfu << (4 * i))) | ((unsigned)k << (4 * i))) : col;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hm[j][i] = best[i];
+        hd[j] = col;
+        const int y = r - 2;                      // the window of output row y is complete: ring rows y-2..y+2
+        if (y >= m.y0) {
+          float o[8];
+          unsigned sel[8], sdy[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { o[i] = -INFINITY; sel[i] = 0x22222222u; sdy[i] = 2; }
+#pragma unroll
+          for (int dy = 0; dy < 5; ++dy) {
+            const int s = (j + 1 + dy) % 5;       // slot of row y - 2 + dy (slot j holds row y + 2)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float v = hm[s][i];
+              const bool take = (v > o[i]) | (v != v);
+              o[i] = take ? v : o[i];
+              sel[i] = take ? hd[s] : sel[i];
+              sdy[i] = take ? (unsigned)dy : sdy[i];
+            }
+          }
+          unsigned a[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] = sdy[i] * 5u + ((sel[i] >> (4 * i)) & 0xfu);
+          const size_t off = (((size_t)m.n * H + y) * W + m.x) * C + (size_t)m.cv * 8;
+          store8(out + off, o);
+          uint2 packed;
+          packed.x = a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24);
+          packed.y = a[4] | (a[5] << 8) | (a[6] << 16) | (a[7] << 24);
+          *reinterpret_cast<uint2*>(idx + off) = packed;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cur[k] = nxt[k];
+      }
+    }
+  }
+}
+
+// Backward march: the thread walks down the OUTPUT rows of its column; each of the 5 x 8 (column, channel) elements of a row
+// belongs to at most one input row of this column (its recorded offset says which, if its dx lands on x at all), and that row
+// is only known at run time -- a register ring would need a 5-way compare-select per element (measured: 136 us, more VALU
+// work than the gather above).  The ring therefore lives in LDS, private to the thread ([slot][channel][thread]: conflict-free,
+// no other thread ever touches it, so the sums keep program order and the result is deterministic): one ds_add_f32 per hit.
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_march_kernel(const T* __restrict__ gout, const uint8_t* __restrict__ idx, int N,
+                                                                        int H, int W, int C, int TH, int strips, T* __restrict__ gin) {
+  __shared__ float ring[5 * 8 * TD_THREADS];
+  const MarchCoord m = march_coord(N, H, W, C, TH, strips);
+  if (!m.live) return;
+  float* mine = ring + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 40; ++e) mine[e * TD_THREADS] = 0.f;
+  const size_t nb = (size_t)m.n * H * W * C + (size_t)m.cv * 8;
+  bool okx[5];
+  size_t xo[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int xx = m.x + k - 2;
+    okx[k] = xx >= 0 && xx < W;
+    xo[k] = (size_t)(okx[k] ? xx : m.x) * C;
+  }
+  const int rstart = m.y0 - 2, rend = m.y1 + 1;       // output rows that reach the strip's input rows
+  Raw8<T> cur[5], nxt[5];
+  uint2 ci[5], ni[5];
+  {
+    const int rc = rstart < 0 ? 0 : rstart;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const size_t o = nb + (size_t)rc * W * C + xo[k];
+      ci[k] = *reinterpret_cast<const uint2*>(idx + o);
+      cur[k].load(gout + o);
+    }
+  }
+  for (int rbase = rstart; rbase <= rend; rbase += 5) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int r = rbase + j;                        // output row; ring slot j <-> input row r
+      if (r <= rend) {
+        {
+          int rn = r + 1;
+          rn = rn < 0 ? 0 : (rn >= H ? H - 1 : rn);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const size_t o = nb + (size_t)rn * W * C + xo[k];
+            ni[k] = *reinterpret_cast<const uint2*>(idx + o);
+            nxt[k].load(gout + o);
+          }
+        }
+        const bool oky = r >= 0 && r < H;
+        const unsigned jb = (j + 3) % 5;              // slot of input row r - 2 (window row dy = 0)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const bool ok = oky && okx[k];
+          const unsigned w0 = ok ? ci[k].x : 0xfefefefeu, w1 = ok ? ci[k].y : 0xfefefefeu;      // 0xfe: no (dy, dx)
+          const unsigned dx = 4 - k;                  // the window column of output x + k - 2 that lies on x
+          float g[8];
+          cur[k].unpack(g);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const unsigned code = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+            const unsigned dy = (code * 13u) >> 6;    // code / 5 for code <= 24
+            if (code - 5u * dy == dx) {
+              unsigned s = jb + dy;
+              s = s >= 5u ? s - 5u : s;
+              __hip_atomic_fetch_add(mine + (s * 8u + i) * TD_THREADS, g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+        const int y = r - 2;                          // input row y has now seen output rows y-2..y+2
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          a[i] = mine[(jb * 8 + i) * TD_THREADS];
+          mine[(jb * 8 + i) * TD_THREADS] = 0.f;
+        }
+        if (y >= m.y0 && y < m.y1) store8(gin + nb + ((size_t)y * W + m.x) * C, a);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { cur[k] = nxt[k]; ci[k] = ni[k]; }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,18 +399,32 @@ static int run_maxpool3s2(bool fwd, const void* a, const void* aux, int N, int H
 
 template <typename T>
 static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, int W, int C, void* o, void* o2, hipStream_t st) {
+  if (fwd) {
+    // strips of TH rows: enough threads to fill the chip on the small maps, at most (TH + 4) / TH re-read on the large ones
+    int TH = H / 6;
+    TH = TH < 1 ? 1 : (TH > 8 ? 8 : TH);
+    const int strips = (H + TH - 1) / TH;
+    const long long threads = (long long)N * strips * W * (C / 8);
+    const long long nblk = (threads + TD_THREADS - 1) / TD_THREADS;
+    if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((maxpool5_fwd_march_kernel<T>), dim3((unsigned)nblk), dim3(TD_THREADS), 0, st, (const T*)a, N, H, W, C, TH, strips, (T*)o, (uint8_t*)o2);
+    return record_launch_error(hipGetLastError(), "td_maxpool5_fwd");
+  }
+  static const bool old_form = getenv("TD_MAXPOOL_OLD") != nullptr;
+  if (!old_form) {
+    int TH = H / 3;
+    TH = TH < 1 ? 1 : (TH > 16 ? 16 : TH);
+    const int strips = (H + TH - 1) / TH;
+    const long long threads = (long long)N * strips * W * (C / 8);
+    const long long nblk = (threads + TD_THREADS - 1) / TD_THREADS;
+    if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((maxpool5_bwd_march_kernel<T>), dim3((unsigned)nblk), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, TH, strips, (T*)o);
+    return record_launch_error(hipGetLastError(), "td_maxpool5_bwd");
+  }
   const long long total = (long long)N * H * W * (C / 8);
   const unsigned blocks = (unsigned)((total + TD_THREADS - 1) / TD_THREADS);
-  // LDS tiles pay on the large maps (163 vs 202 us at 12x256x48x160, 47 vs 54 us at 24x80); on the small ones the few
-  // tiles leave most of the chip idle (31 vs 17 us at 12x40) and the one-output-per-thread form stays
-  if (fwd && C % (8 * MP_CV) == 0 && (long long)H * W >= 1536 && (long long)N * (C / (8 * MP_CV)) <= 65535) {
-    const dim3 grid((W + MP_TW - 1) / MP_TW, (H + MP_TH - 1) / MP_TH, N * (C / (8 * MP_CV)));
-    hipLaunchKernelGGL((maxpool5_fwd_lds_kernel<T>), grid, dim3(TD_THREADS), 0, st, (const T*)a, N, H, W, C, (T*)o, (uint8_t*)o2);
-  } else if (fwd)
-    hipLaunchKernelGGL((maxpool5_fwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, N, H, W, C, (T*)o, (uint8_t*)o2);
-  else
-    hipLaunchKernelGGL((maxpool5_bwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, (T*)o);
-  return record_launch_error(hipGetLastError(), fwd ? "td_maxpool5_fwd" : "td_maxpool5_bwd");
+  hipLaunchKernelGGL((maxpool5_bwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, (T*)o);
+  return record_launch_error(hipGetLastError(), "td_maxpool5_bwd");
 }
 
 }  // namespace td
