@@ -268,8 +268,9 @@ int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype, const flo
  *   separate statistics (stacked passes, as td_bn_fwd).
  *   stat_partials (may be NULL): [groups, S, N, 2] f32 with S = td_conv1x1_stat_rows(M, groups, N): (sum y, sum y^2) over the
  *   rows of each row tile, of the bf16-rounded outputs -- the layout td_bn_fwd_from_partials consumes.
- * td_bn_fwd_from_partials: td_bn_fwd without its statistics pass (finalize + apply): mean / invstd / running statistics
- *   from `partials` [groups, stat_rows, C, 2], then y = relu?( (x - mean) * invstd * gamma + beta [+ residual] ).
+ * td_bn_fwd_from_partials: td_bn_fwd without its statistics pass: mean / invstd / running statistics from `partials`
+ *   [groups, stat_rows, C, 2] (finished in the prologue of the apply kernel; the buffer is SCRATCH: more than 96 rows are first
+ *   reduced in place), then y = relu?( (x - mean) * invstd * gamma + beta [+ residual] ).
  * td_conv1x1_wgrad: the weight gradient of the same convolution, dW[n, k] = sum_m dY[m, n] * X[src(m), k] (autograd of the
  *   Conv2d above), on the MFMA through transposed LDS reads (ds_read_b64_tr_b16); M is cut into row ranges whose fp32 partial
  *   tiles a second kernel adds in order (deterministic; dW in bf16 or f32: dw_dtype).
@@ -291,7 +292,7 @@ int td_conv1x1_wgrad(const void* dy, const void* x, long long M, int K, int N, i
                      float* workspace, td_stream_t stream);
 int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
-                            int groups, int C, const float* partials, int stat_rows, void* y, float* save_mean,
+                            int groups, int C, float* partials, int stat_rows, void* y, float* save_mean,
                             float* save_invstd, td_stream_t stream);
 
 /*

@@ -140,28 +140,21 @@ __device__ __forceinline__ void bn_sum_partials(const float* __restrict__ ws, in
   }
 }
 
-__global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_fwd_kernel(const float* __restrict__ ws, int S, int C, long long M,
-                                                                        int G, float eps, float momentum,
-                                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                        float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  // groups in order: the running statistics receive one momentum update per group, exactly like G separate calls
-  for (int grp = 0; grp < G; ++grp) {
-    float A, B;
-    bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
-    if (threadIdx.x < BN_FIN_CH) {
-      const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
-      const double m = (double)A / (double)M;
-      double var = (double)B / (double)M - m * m;      // biased variance, formed in double
-      var = var > 0.0 ? var : 0.0;
-      save_mean[(size_t)grp * C + c] = (float)m;
-      save_invstd[(size_t)grp * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-      if (running_mean) {
-        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-      }
-    }
-    __syncthreads();      // bn_sum_partials' LDS is reused by the next group
+// More than BN_PRO_MAX_S partial rows (the two shallow ResNet stages: up to 1440 row tiles per group): shrink them first, in
+// place -- block (cg, q) sums rows [q Sq, (q + 1) Sq) of its 16 channels in order and leaves the result in row q Sq, so the
+// consumer's prologue (bn_tile_sums with row stride Sq) sees at most BN_PRO_MAX_S rows.  Q times more blocks than a one-stage
+// finalize with 1/Q of its dependent loads each: ~3 us where the finalize kernels took 7-8 us, and no finalize kernel at all
+// for the layers with few rows.
+__global__ __launch_bounds__(BN_FIN_THREADS) void bn_shrink_kernel(float* __restrict__ ws, int S, int C, int Sq) {
+  const int q = blockIdx.y, grp = blockIdx.z;
+  float* w = ws + ((size_t)grp * S + (size_t)q * Sq) * C * 2;
+  const int rows = S - q * Sq < Sq ? S - q * Sq : Sq;
+  float A, B;
+  bn_sum_partials(w, rows, C, blockIdx.x, A, B);       // its barrier orders every read of row 0 before the write below
+  if (threadIdx.x < BN_FIN_CH) {
+    float* o = w + ((size_t)blockIdx.x * BN_FIN_CH + threadIdx.x) * 2;
+    o[0] = A;
+    o[1] = B;
   }
 }
 
@@ -247,7 +240,7 @@ constexpr int BN_PRO_MAX_S = 96;
 constexpr int BN_PRO_PARTS = BN_THREADS / 64;
 constexpr int BN_PRO_DEPTH = BN_PRO_MAX_S / BN_PRO_PARTS;
 // (A, B) = sums over the S partial rows for channel 64 * ct + threadIdx.x, valid in threads 0..63; block-uniform call
-__device__ __forceinline__ void bn_tile_sums(const float* __restrict__ ws, int S, int C, int ct, float& A, float& B) {
+__device__ __forceinline__ void bn_tile_sums(const float* __restrict__ ws, int S, int stride, int C, int ct, float& A, float& B) {
   __shared__ float red[2][BN_PRO_PARTS][64];
   const int tid = threadIdx.x, c = tid & 63, part = tid >> 6;
   const float* p = ws + ((size_t)ct * 64 + c) * 2;
@@ -255,7 +248,7 @@ __device__ __forceinline__ void bn_tile_sums(const float* __restrict__ ws, int S
 #pragma unroll
   for (int u = 0; u < BN_PRO_DEPTH; ++u) {
     const int row = part + BN_PRO_PARTS * u;
-    v[u] = *reinterpret_cast<const float2*>(p + (size_t)(row < S ? row : 0) * C * 2);
+    v[u] = *reinterpret_cast<const float2*>(p + (size_t)(row < S ? row : 0) * stride * C * 2);
   }
   float a = 0.f, b = 0.f;
 #pragma unroll
@@ -277,8 +270,8 @@ __device__ __forceinline__ void bn_tile_sums(const float* __restrict__ ws, int S
 }
 
 struct BnFinFwd {       // forward statistics formed in bn_apply's prologue (FIN = true)
-  const float* ws;      // [G, S, C, 2] partial (sum x, sum x^2)
-  int S, G;
+  const float* ws;      // [G, rows, C, 2] partial (sum x, sum x^2); rows 0, stride, 2 stride, ... (S of them) are summed
+  int S, stride, rows, G;
   float eps, momentum;
   float* running_mean;
   float* running_var;
@@ -286,8 +279,8 @@ struct BnFinFwd {       // forward statistics formed in bn_apply's prologue (FIN
   float* save_invstd;
 };
 struct BnFinBwd {       // backward coefficients formed in bn_dx's prologue (FIN = true)
-  const float* ws;      // [G, S, C, 2] partial (sum g, sum g (x - mean))
-  int S, G;
+  const float* ws;      // [G, rows, C, 2] partial (sum g, sum g (x - mean)), read like BnFinFwd::ws
+  int S, stride, rows, G;
   float* dgamma;
   float* dbeta;
 };
@@ -309,7 +302,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
     __shared__ float s_sc[64], s_sh[64];
     const int c = blockIdx.x * 64 + (tid & 63);
     float A, B;
-    bn_tile_sums(fin.ws + (size_t)grp * fin.S * C * 2, fin.S, C, blockIdx.x, A, B);
+    bn_tile_sums(fin.ws + (size_t)grp * fin.rows * C * 2, fin.S, fin.stride, C, blockIdx.x, A, B);
     if (tid < 64) {
       const double m = (double)A / (double)M;
       double var = (double)B / (double)M - m * m;      // biased variance, formed in double
@@ -329,7 +322,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
       if (tid < 64) { rm = fin.running_mean[c]; rv = fin.running_var[c]; }
       for (int g2 = 0; g2 < fin.G; ++g2) {
         float A2 = A, B2 = B;
-        if (g2 != 0) bn_tile_sums(fin.ws + (size_t)g2 * fin.S * C * 2, fin.S, C, blockIdx.x, A2, B2);
+        if (g2 != 0) bn_tile_sums(fin.ws + (size_t)g2 * fin.rows * C * 2, fin.S, fin.stride, C, blockIdx.x, A2, B2);
         if (tid < 64) {
           const double m = (double)A2 / (double)M;
           double var = (double)B2 / (double)M - m * m;
@@ -379,39 +372,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
   }
 }
 
-// dgamma, dbeta (summed over the statistics groups) and per group the dx coefficients  dx = k0 * g + k1 * x + k2
-__global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_bwd_kernel(const float* __restrict__ ws, int S, int C, long long M,
-                                                                        int G, const float* __restrict__ gamma,
-                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                        float* __restrict__ coef) {
-  float dg_tot = 0.f, db_tot = 0.f;
-  for (int grp = 0; grp < G; ++grp) {
-    float A, B;
-    bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
-    if (threadIdx.x < BN_FIN_CH) {
-      const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
-      const float is = invstd[(size_t)grp * C + c], mu = mean[(size_t)grp * C + c];
-      const float dg = B * is;                     // sum g * xhat
-      dg_tot += dg;
-      db_tot += A;
-      const float k0 = gamma[c] * is;
-      const float inv_m = 1.f / (float)M;
-      const float k1 = -k0 * is * dg * inv_m;      // multiplies (x - mean)
-      float* co = coef + ((size_t)grp * C + c) * 3;
-      co[0] = k0;
-      co[1] = k1;
-      co[2] = -k0 * A * inv_m - k1 * mu;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < BN_FIN_CH) {
-    const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
-    dgamma[c] = dg_tot;
-    dbeta[c] = db_tot;
-  }
-}
-
 template <typename T, bool FIN = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ coef, const float* __restrict__ mean,
@@ -431,7 +391,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
     const int c = blockIdx.x * 64 + (tid & 63);
     const float inv_m = 1.f / (float)M;
     float A, B;
-    bn_tile_sums(fin.ws + (size_t)grp * fin.S * C * 2, fin.S, C, blockIdx.x, A, B);
+    bn_tile_sums(fin.ws + (size_t)grp * fin.rows * C * 2, fin.S, fin.stride, C, blockIdx.x, A, B);
     if (tid < 64) {
       const float is = invstd[(size_t)grp * C + c], mu = mean[(size_t)grp * C + c];
       const float dg = B * is;                     // sum g * xhat
@@ -445,7 +405,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
       float dg_tot = 0.f, db_tot = 0.f;
       for (int g2 = 0; g2 < fin.G; ++g2) {
         float A2 = A, B2 = B;
-        if (g2 != 0) bn_tile_sums(fin.ws + (size_t)g2 * fin.S * C * 2, fin.S, C, blockIdx.x, A2, B2);
+        if (g2 != 0) bn_tile_sums(fin.ws + (size_t)g2 * fin.rows * C * 2, fin.S, fin.stride, C, blockIdx.x, A2, B2);
         if (tid < 64) {
           dg_tot += B2 * invstd[(size_t)g2 * C + c];
           db_tot += A2;
@@ -522,24 +482,26 @@ static inline int bn_rows_per_split(long long M, int S) {
   return (int)((r + BN_RY - 1) / BN_RY * BN_RY);
 }
 
-// finalize (own launch, or in the apply kernel's prologue when the partial rows are few) + apply, from partial sums
+// the partial rows a consumer prologue sums: all S of them, or -- after bn_shrink_kernel -- every Sq-th
+struct BnRows { int n, stride; };
+static BnRows shrink_partials(float* partials, int S, int G, int C, hipStream_t st) {
+  if (S <= BN_PRO_MAX_S) return {S, 1};
+  const int Sq = (S + BN_PRO_MAX_S - 1) / BN_PRO_MAX_S, Q = (S + Sq - 1) / Sq;
+  hipLaunchKernelGGL(bn_shrink_kernel, dim3(C / BN_FIN_CH, Q, G), dim3(BN_FIN_THREADS), 0, st, partials, S, C, Sq);
+  return {Q, Sq};
+}
+
+// statistics (in the apply kernel's prologue) + apply, from partial sums; `partials` is reduced in place when S > BN_PRO_MAX_S
 template <typename T>
 static void launch_bn_finalize_apply(const void* x, const void* res, const float* gamma, const float* beta, float* rmean, float* rvar,
-                                     float momentum, float eps, int relu, long long Mg, int G, int C, const float* partials, int S, void* y,
+                                     float momentum, float eps, int relu, long long Mg, int G, int C, float* partials, int S, void* y,
                                      float* save_mean, float* save_invstd, hipStream_t st) {
-  const bool pro = S <= BN_PRO_MAX_S;
-  const int S2 = bn_splits(Mg, C, (pro ? 1024 : 2048) / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const BnRows rows = shrink_partials(partials, S, G, C, st);
+  const int S2 = bn_splits(Mg, C, 1024 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
   const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
-  if (pro) {
-    const BnFinFwd fin = {partials, S, G, eps, momentum, rmean, rvar, save_mean, save_invstd};
-    hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
-                       (const float*)nullptr, (const float*)nullptr, Mg, C, rps2, relu, (T*)y, fin);
-    return;
-  }
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, partials, S, C, Mg, G, eps, momentum, rmean, rvar,
-                     save_mean, save_invstd);
-  hipLaunchKernelGGL((bn_apply_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
-                     (const float*)save_mean, (const float*)save_invstd, Mg, C, rps2, relu, (T*)y, BnFinFwd{});
+  const BnFinFwd fin = {partials, rows.n, rows.stride, S, G, eps, momentum, rmean, rvar, save_mean, save_invstd};
+  hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
+                     (const float*)nullptr, (const float*)nullptr, Mg, C, rps2, relu, (T*)y, fin);
 }
 
 template <typename T>
@@ -561,22 +523,14 @@ static int run_bn_bwd(const void* dy, const void* x, const void* y, const float*
   const long long Mg = M / G;
   const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
-  float* coef = ws + (size_t)2 * S_eff * C * G;
   hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                      (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
-  const bool pro = S_eff <= BN_PRO_MAX_S;
-  const int S2 = bn_splits(Mg, C, (pro ? 1024 : 2048) / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const BnRows rows = shrink_partials(ws, S_eff, G, C, st);
+  const int S2 = bn_splits(Mg, C, 1024 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
   const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
-  if (pro) {
-    const BnFinBwd fin = {ws, S_eff, G, dgamma, dbeta};
-    hipLaunchKernelGGL((bn_dx_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)nullptr,
-                       mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, fin);
-  } else {
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, Mg, G, gamma, mean,
-                       invstd, dgamma, dbeta, coef);
-    hipLaunchKernelGGL((bn_dx_kernel<T, false>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)coef,
-                       mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, BnFinBwd{});
-  }
+  const BnFinBwd fin = {ws, rows.n, rows.stride, S_eff, G, dgamma, dbeta};
+  hipLaunchKernelGGL((bn_dx_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)nullptr,
+                     mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, fin);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
@@ -668,11 +622,12 @@ extern "C" int td_bn_bwd(const void* dy, const void* x, const void* y, int dtype
   return TD_ERR_UNSUPPORTED;
 }
 
-// Forward with the partial sums already formed by the producing kernel (td_conv1x1_fwd's epilogue): finalize + apply (one
-// launch when stat_rows <= 96, else two) and no statistics pass over x.  partials: [groups, stat_rows, C, 2] f32.
+// Forward with the partial sums already formed by the producing kernel (td_conv1x1_fwd's epilogue): the statistics are finished
+// in the apply kernel's prologue (one launch when stat_rows <= 96; above that a shrink launch first reduces `partials` IN PLACE)
+// and there is no statistics pass over x.  partials: [groups, stat_rows, C, 2] f32, scratch after the call.
 extern "C" int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
                                        float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
-                                       int groups, int C, const float* partials, int stat_rows, void* y, float* save_mean,
+                                       int groups, int C, float* partials, int stat_rows, void* y, float* save_mean,
                                        float* save_invstd, td_stream_t stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !partials || stat_rows < 1 || !bn_shape_ok(M, groups, C))
     return TD_ERR_BAD_ARG;

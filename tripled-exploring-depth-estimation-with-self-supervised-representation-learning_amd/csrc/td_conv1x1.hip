@@ -155,7 +155,10 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_kernel(
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid >> 1, wk = wid & 1;
-  const int nt = blockIdx.x % tiles_n, kt = (blockIdx.x / tiles_n) % tiles_k, sp = blockIdx.x / (tiles_n * tiles_k);
+  // all (n, k) tiles of one row range read the same rows of dY and X: with the round-robin dispatch every XCD would pull every
+  // row range through its own L2 (8 x the operand bytes over the fabric); the remap gives each XCD a contiguous run of ranges
+  const int L = cv_xcd_tile(blockIdx.x, gridDim.x);
+  const int nt = L % tiles_n, kt = (L / tiles_n) % tiles_k, sp = L / (tiles_n * tiles_k);
   const int n0 = nt * WG_T, k0 = kt * WG_T;
   const long long m_lo = (long long)sp * rows_per_split;
   const long long m_hi = (m_lo + rows_per_split < M) ? m_lo + rows_per_split : M;

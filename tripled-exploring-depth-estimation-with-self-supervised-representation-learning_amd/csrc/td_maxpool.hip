@@ -5,8 +5,6 @@
 // Tie-break and NaN handling follow ATen's max_pool2d: row-major scan, strict '>', NaN wins.
 #include <hip/hip_bf16.h>
 
-#include <cstdlib>
-
 #include "td_common.h"
 #include "td_vec8.h"
 
@@ -56,18 +54,19 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// Column-march forms.  The kernels above are latency chains: the LDS tile is staged by 7-8 dependent global loads per thread
-// and the gather backward takes its 25 gradient loads under divergent branches, one L2 round trip after the other
-// (163 / 136 us on the 47 MB map of the finest CRP stage: 0.7 TB/s of the 118 MB each has to move).  Here one thread owns a
-// pixel column x 8 channels of a strip of rows and walks down it: every row costs 5 unconditional 16-byte loads (x-2..x+2, the
-// horizontal neighbours come out of L1), the next row's loads are issued before this row's arithmetic, and the vertical
-// window lives in a 5-deep register ring -- no LDS, no barrier, no branch on data.
-//   forward : row maximum + its first column (ATen's scan order is row-major, so "first maximum" = first row holding the
-//             maximum, first column inside that row; "NaN wins" = last NaN = last row holding one, last NaN inside it: the
-//             two-stage scan below keeps both rules), then the same scan down the 5 ring rows;
-//   backward: output row r adds into the ring slot of input row r + dy - 2 where its recorded offset says (dy, dx) and dx
-//             matches the column it was loaded from; the slot of input row r - 2 is complete after row r and is written.
-// Rows/columns outside the map load a clamped address and are replaced by -inf / "no offset".
+// Column-march forward.  A tiled forward (LDS tile staged by 7-8 dependent global loads per thread, then 25 LDS reads per
+// output) ran at 163 us on the 47 MB map of the finest CRP stage, 0.7 TB/s of the 118 MB it has to move.  Here one thread owns
+// a pixel column x 8 channels of a strip of rows and walks down it: every row costs 5 unconditional 16-byte loads (x-2..x+2,
+// the horizontal neighbours come out of L1), the next row's loads are issued before this row's arithmetic, and the vertical
+// window lives in a 5-deep register ring -- no LDS, no barrier, no branch on data: 65 us, now bound by the vector ALU (a
+// wave64 instruction occupies its SIMD for 4 cycles; ~600 of them per 8 outputs).
+//   row maximum + its first column (ATen's scan order is row-major, so "first maximum" = first row holding the maximum, first
+//   column inside that row; "NaN wins" = last NaN = last row holding one, last NaN inside it: the two-stage scan keeps both
+//   rules), then the same scan down the 5 ring rows.
+// Rows/columns outside the map load a clamped address and are replaced by -inf.
+// The backward stays the gather above: the same march needs a 5-way compare-select per (column, channel) element to find the
+// input row an output's offset points at (136 us with a register ring, 167 us with a thread-private LDS ring and ds_add_f32
+// -- both more vector-ALU work than the gather's 124 us).
 template <typename T>
 struct Raw8;
 template <>
@@ -218,91 +217,6 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_march_kernel(const T*
   }
 }
 
-// Backward march: the thread walks down the OUTPUT rows of its column; each of the 5 x 8 (column, channel) elements of a row
-// belongs to at most one input row of this column (its recorded offset says which, if its dx lands on x at all), and that row
-// is only known at run time -- a register ring would need a 5-way compare-select per element (measured: 136 us, more VALU
-// work than the gather above).  The ring therefore lives in LDS, private to the thread ([slot][channel][thread]: conflict-free,
-// no other thread ever touches it, so the sums keep program order and the result is deterministic): one ds_add_f32 per hit.
-template <typename T>
-__global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_march_kernel(const T* __restrict__ gout, const uint8_t* __restrict__ idx, int N,
-                                                                        int H, int W, int C, int TH, int strips, T* __restrict__ gin) {
-  __shared__ float ring[5 * 8 * TD_THREADS];
-  const MarchCoord m = march_coord(N, H, W, C, TH, strips);
-  if (!m.live) return;
-  float* mine = ring + threadIdx.x;
-#pragma unroll
-  for (int e = 0; e < 40; ++e) mine[e * TD_THREADS] = 0.f;
-  const size_t nb = (size_t)m.n * H * W * C + (size_t)m.cv * 8;
-  bool okx[5];
-  size_t xo[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int xx = m.x + k - 2;
-    okx[k] = xx >= 0 && xx < W;
-    xo[k] = (size_t)(okx[k] ? xx : m.x) * C;
-  }
-  const int rstart = m.y0 - 2, rend = m.y1 + 1;       // output rows that reach the strip's input rows
-  Raw8<T> cur[5], nxt[5];
-  uint2 ci[5], ni[5];
-  {
-    const int rc = rstart < 0 ? 0 : rstart;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const size_t o = nb + (size_t)rc * W * C + xo[k];
-      ci[k] = *reinterpret_cast<const uint2*>(idx + o);
-      cur[k].load(gout + o);
-    }
-  }
-  for (int rbase = rstart; rbase <= rend; rbase += 5) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int r = rbase + j;                        // output row; ring slot j <-> input row r
-      if (r <= rend) {
-        {
-          int rn = r + 1;
-          rn = rn < 0 ? 0 : (rn >= H ? H - 1 : rn);
-#pragma unroll
-          for (int k = 0; k < 5; ++k) {
-            const size_t o = nb + (size_t)rn * W * C + xo[k];
-            ni[k] = *reinterpret_cast<const uint2*>(idx + o);
-            nxt[k].load(gout + o);
-          }
-        }
-        const bool oky = r >= 0 && r < H;
-        const unsigned jb = (j + 3) % 5;              // slot of input row r - 2 (window row dy = 0)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          const bool ok = oky && okx[k];
-          const unsigned w0 = ok ? ci[k].x : 0xfefefefeu, w1 = ok ? ci[k].y : 0xfefefefeu;      // 0xfe: no (dy, dx)
-          const unsigned dx = 4 - k;                  // the window column of output x + k - 2 that lies on x
-          float g[8];
-          cur[k].unpack(g);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const unsigned code = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
-            const unsigned dy = (code * 13u) >> 6;    // code / 5 for code <= 24
-            if (code - 5u * dy == dx) {
-              unsigned s = jb + dy;
-              s = s >= 5u ? s - 5u : s;
-              __hip_atomic_fetch_add(mine + (s * 8u + i) * TD_THREADS, g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          }
-        }
-        const int y = r - 2;                          // input row y has now seen output rows y-2..y+2
-        float a[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          a[i] = mine[(jb * 8 + i) * TD_THREADS];
-          mine[(jb * 8 + i) * TD_THREADS] = 0.f;
-        }
-        if (y >= m.y0 && y < m.y1) store8(gin + nb + ((size_t)y * W + m.x) * C, a);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { cur[k] = nxt[k]; ci[k] = ni[k]; }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // ResNet stem pool: MaxPool2d(kernel 3, stride 2, padding 1) (reference: mono/model/mono_fm_joint/resnet.py:101),
 // same conventions: one thread = one output pixel x 8 channels, 1-byte window offset dy*3+dx, gather-form backward
@@ -409,17 +323,6 @@ static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, i
     if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((maxpool5_fwd_march_kernel<T>), dim3((unsigned)nblk), dim3(TD_THREADS), 0, st, (const T*)a, N, H, W, C, TH, strips, (T*)o, (uint8_t*)o2);
     return record_launch_error(hipGetLastError(), "td_maxpool5_fwd");
-  }
-  static const bool old_form = getenv("TD_MAXPOOL_OLD") != nullptr;
-  if (!old_form) {
-    int TH = H / 3;
-    TH = TH < 1 ? 1 : (TH > 16 ? 16 : TH);
-    const int strips = (H + TH - 1) / TH;
-    const long long threads = (long long)N * strips * W * (C / 8);
-    const long long nblk = (threads + TD_THREADS - 1) / TD_THREADS;
-    if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((maxpool5_bwd_march_kernel<T>), dim3((unsigned)nblk), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, TH, strips, (T*)o);
-    return record_launch_error(hipGetLastError(), "td_maxpool5_bwd");
   }
   const long long total = (long long)N * H * W * (C / 8);
   const unsigned blocks = (unsigned)((total + TD_THREADS - 1) / TD_THREADS);
