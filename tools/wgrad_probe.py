@@ -27,6 +27,7 @@ def timeit(fn, iters=20):
 
 
 def main():
+    only_td = "--only-td" in sys.argv          # under rocprofv3: just the hand-written kernels, per-kernel GPU time from the trace
     torch.backends.cudnn.benchmark = True
     import tripled_amd  # noqa: F401
     from tripled_amd import native
@@ -62,7 +63,7 @@ def main():
         def td_w():      # the hand-written kernel + its ordered slab sum (csrc/td_conv1x1.hip)
             native.check(lib.td_conv1x1_wgrad(_raw(dy), _raw(x), M, K, N, H, W, 1, native.DTYPE_CODES[dw.dtype], _raw(dw), native.ptr(ws), st), "wgrad")
 
-        t = [timeit(both), timeit(dgrad), timeit(mm_d), timeit(mm_w), timeit(td_w)]
+        t = [0.0, 0.0, 0.0, 0.0, timeit(td_w)] if only_td else [timeit(both), timeit(dgrad), timeit(mm_d), timeit(mm_w), timeit(td_w)]
         for i in range(5):
             tot[i] += t[i]
         print("%-24s %10.1f %10.1f %10.1f %10.1f %10.1f" % (",".join(map(str, (B, H, W, K, N))), *t))

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(TD_THREADS) void conv1x1_wgrad_reduce_kernel(const 
 
 static inline int wg_splits(long long M, int K, int N) {
   const long long tiles = (long long)(N / WG_T) * (K / WG_T);
-  long long p = (1024 + tiles - 1) / tiles;               // ~4 workgroups per CU
+  long long p = (768 + tiles - 1) / tiles;                // 3 workgroups per CU = what its LDS holds at once (768 / 512 / 1024: 355 / 377 / 396 us over the probe's shapes)
   const long long by_rows = (M + 4 * WG_T - 1) / (4 * WG_T);   // at least four stages per workgroup
   if (p > by_rows) p = by_rows;
   if (p > 512) p = 512;
