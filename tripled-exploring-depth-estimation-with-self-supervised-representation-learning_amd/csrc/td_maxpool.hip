@@ -217,6 +217,102 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_march_kernel(const T*
   }
 }
 
+// Scatter backward for the large maps.  The gather above tests 25 recorded offsets per input element (~800 vector-ALU
+// instructions per 8 channels: 124 us on the finest CRP map, ALU-bound); an OUTPUT element knows its one target.  A workgroup
+// takes 32 output columns x 64 channels (8 channel vectors fastest: a wave reads whole 128-byte pixel slabs) of a strip of
+// rows and walks down it, rows requested 4 iterations ahead.  The accumulators are an LDS ring of 6 input rows x 32 columns,
+// one array per channel-in-vector i (the compiler then knows the 8 read-add-writes of a thread are independent and
+// pipelines them).  Two outputs of one row reach the same input element only from columns less than 5 apart, so the threads
+// take turns by column % 5, a barrier between turns: inside a turn every address has one writer -- plain ds_read / add /
+// ds_write, a fixed summation order, no atomics.  After the turns of output row r input row r - 2 has seen rows r-4..r:
+// its slot is written out for the 28 interior columns the workgroup owns (tiles overlap by 2 + 2 output columns) and zeroed;
+// with 6 slots the slot being read out is never a target of the next row's adds.  65.7 us on the finest map (24.3 at 24x80).
+// Measured and dropped on the way: ds_add_f32 instead of turns (~0.3 lanes per clock: 235 us; integer ds_add_u32 runs the same
+// kernel in 43 us); turns by recorded dx with per-element predicates (93 us); wave-owned channel vectors so that no barrier
+// is needed at all (lane = column: every lane another 128-byte line, 112 us).
+constexpr int MS_COLS = 32, MS_OWN = MS_COLS - 4, MS_SLOTS = 6;
+constexpr int MS_PLANE = MS_SLOTS * MS_COLS * 8;             // floats per channel-in-vector array: [slot][column][vector]
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_scatter_kernel(const T* __restrict__ gout, const uint8_t* __restrict__ idx, int N,
+                                                                          int H, int W, int C, int TH, T* __restrict__ gin) {
+  __shared__ float t0[MS_PLANE], t1[MS_PLANE], t2[MS_PLANE], t3[MS_PLANE], t4[MS_PLANE], t5[MS_PLANE], t6[MS_PLANE], t7[MS_PLANE];
+  float* const plane[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
+  const int tid = threadIdx.x, cv = tid & 7, lc = tid >> 3;   // channel vectors fastest: a wave reads 8 whole 128-byte pixel slabs
+  const int slabs = C >> 6;
+  const int n = blockIdx.z / slabs, slab = blockIdx.z - n * slabs;
+  const int ox = (int)blockIdx.x * MS_OWN - 2 + lc;          // this lane's output column (and, for 2 <= lc < 30, its input column)
+  const int y0 = (int)blockIdx.y * TH, y1 = y0 + TH < H ? y0 + TH : H;
+  const bool okx = ox >= 0 && ox < W;
+  const bool own = okx && lc >= 2 && lc < 2 + MS_OWN;
+  const int turn = lc % 5;
+  const int me = lc * 8 + cv;                                // (slot 0, own column, own vector); a slot is MS_COLS * 8 floats, a column 8
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int sl = 0; sl < MS_SLOTS; ++sl) plane[i][sl * (MS_COLS * 8) + me] = 0.f;
+  const size_t nb = (size_t)n * H * W * C + (size_t)slab * 64 + (size_t)cv * 8;
+  const size_t xoff = (size_t)(okx ? ox : 0) * C;
+  const int rstart = y0 - 2, rend = y1 + 1;
+  constexpr int MS_AHEAD = 4;                                // rows requested ahead of use
+  Raw8<T> gq[MS_AHEAD];
+  uint2 iq[MS_AHEAD];
+#pragma unroll
+  for (int j = 0; j < MS_AHEAD; ++j) {
+    int rc = rstart + j;
+    rc = rc < 0 ? 0 : (rc >= H ? H - 1 : rc);
+    const size_t o = nb + (size_t)rc * W * C + xoff;
+    iq[j] = *reinterpret_cast<const uint2*>(idx + o);
+    gq[j].load(gout + o);
+  }
+  int b = 4;                                                 // slot of input row r - 2 = (r - rstart + 4) % 6
+  for (int rb = rstart; rb <= rend; rb += MS_AHEAD) {
+#pragma unroll
+    for (int j = 0; j < MS_AHEAD; ++j) {
+      const int r = rb + j;                                  // rows past rend (the group of MS_AHEAD is always completed): no adds, no store
+      const bool ok = okx && r >= 0 && r < H && r <= rend;
+      const uint2 ci = iq[j];
+      float g[8];
+      gq[j].unpack(g);
+      {
+        int rn = r + MS_AHEAD;
+        rn = rn < 0 ? 0 : (rn >= H ? H - 1 : rn);
+        const size_t o = nb + (size_t)rn * W * C + xoff;
+        iq[j] = *reinterpret_cast<const uint2*>(idx + o);
+        gq[j].load(gout + o);
+      }
+      int off[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned code = ((i < 4 ? ci.x : ci.y) >> (8 * (i & 3))) & 0xffu;
+        const unsigned dy = (code * 13u) >> 6;               // code / 5 for code <= 24
+        const int dxs = (int)(code - 5u * dy) - 2;           // target column - own column
+        const bool hit = ok && (unsigned)(lc + dxs) < (unsigned)MS_COLS;
+        unsigned sl = (unsigned)b + dy;                      // slot of input row r + dy - 2
+        sl = sl >= (unsigned)MS_SLOTS ? sl - MS_SLOTS : sl;
+        off[i] = hit ? (int)sl * (MS_COLS * 8) + dxs * 8 + me : b * (MS_COLS * 8) + me;
+        g[i] = hit ? g[i] : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        if (turn == p) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) plane[i][off[i]] += g[i];
+        }
+        __syncthreads();       // the next turn (and the read-out below) reads what other threads just wrote
+      }
+      const int y = r - 2;
+      float a[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        a[i] = plane[i][b * (MS_COLS * 8) + me];
+        plane[i][b * (MS_COLS * 8) + me] = 0.f;
+      }
+      if (own && y >= y0 && y < y1) store8(gin + nb + ((size_t)y * W + ox) * C, a);
+      b = b + 1 == MS_SLOTS ? 0 : b + 1;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ResNet stem pool: MaxPool2d(kernel 3, stride 2, padding 1) (reference: mono/model/mono_fm_joint/resnet.py:101),
 // same conventions: one thread = one output pixel x 8 channels, 1-byte window offset dy*3+dx, gather-form backward
@@ -323,6 +419,18 @@ static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, i
     if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((maxpool5_fwd_march_kernel<T>), dim3((unsigned)nblk), dim3(TD_THREADS), 0, st, (const T*)a, N, H, W, C, TH, strips, (T*)o, (uint8_t*)o2);
     return record_launch_error(hipGetLastError(), "td_maxpool5_fwd");
+  }
+  if (C % 64 == 0 && (long long)H * W >= 1536 && (long long)N * (C / 64) <= 65535 && (H + 3) / 4 <= 65535) {
+    // strips of TH rows ((TH + 4) / TH of the rows are read): as many as keep the launch within the 3 workgroups per CU the
+    // LDS ring allows (a second, mostly empty round of workgroups would double the time), at least 8 rows each
+    const long long per_strip = (long long)((W + MS_OWN - 1) / MS_OWN) * N * (C / 64);
+    long long strips = (256 * 3) / per_strip;
+    strips = strips < 1 ? 1 : strips;
+    int TH = (int)((H + strips - 1) / strips);
+    TH = TH < 8 ? 8 : TH;
+    const dim3 grid((W + MS_OWN - 1) / MS_OWN, (H + TH - 1) / TH, N * (C / 64));
+    hipLaunchKernelGGL((maxpool5_bwd_scatter_kernel<T>), grid, dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, TH, (T*)o);
+    return record_launch_error(hipGetLastError(), "td_maxpool5_bwd");
   }
   const long long total = (long long)N * H * W * (C / 8);
   const unsigned blocks = (unsigned)((total + TD_THREADS - 1) / TD_THREADS);
