@@ -297,6 +297,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
   const long long r0 = base + (long long)blockIdx.y * rows_per_split;
   const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
+  // the first rows are requested BEFORE the statistics prologue: its dependent chain (partials -> LDS -> mean / invstd) is a
+  // 2-3 us round trip that would otherwise stand in front of every block's first load
+  Raw8<T> qx[BN_UNROLL], qr[BN_UNROLL];
+  bool ok[BN_UNROLL];
+#define BN_APPLY_ISSUE(rr0)                                                       \
+  {                                                                               \
+    _Pragma("unroll") for (int u = 0; u < BN_UNROLL; ++u) {                       \
+      const long long rr = (rr0) + (long long)u * BN_RY;                          \
+      ok[u] = rr < r1;                                                            \
+      const size_t off = (size_t)(ok[u] ? rr : (rr0)) * C + col;                  \
+      qx[u].load(x + off);                                                        \
+      if (res) qr[u].load(res + off);                                             \
+    }                                                                             \
+  }
+  long long r = r0 + ry;
+  if (r < r1) BN_APPLY_ISSUE(r)
   float sc[8], sh[8];
   if constexpr (FIN) {
     __shared__ float s_sc[64], s_sh[64];
@@ -346,17 +362,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
       sh[i] = beta[col + i] - mean[col + i] * sc[i];
     }
   }
-  for (long long r = r0 + ry; r < r1; r += BN_UNROLL * BN_RY) {
+  for (; r < r1; r += BN_UNROLL * BN_RY) {
     float vx[BN_UNROLL][8], vr[BN_UNROLL][8];
-    bool ok[BN_UNROLL];
+    bool okc[BN_UNROLL];
 #pragma unroll
     for (int u = 0; u < BN_UNROLL; ++u) {
-      const long long rr = r + (long long)u * BN_RY;
-      ok[u] = rr < r1;
-      const size_t off = (size_t)(ok[u] ? rr : r) * C + col;
-      load8(x + off, vx[u]);
-      if (res) load8(res + off, vr[u]);
+      qx[u].unpack(vx[u]);
+      if (res) qr[u].unpack(vr[u]);
+      okc[u] = ok[u];
     }
+    const long long rn = r + BN_UNROLL * BN_RY;           // the next rows are on their way while these are written
+    if (rn < r1) BN_APPLY_ISSUE(rn)
 #pragma unroll
     for (int u = 0; u < BN_UNROLL; ++u) {
       float o[8];
@@ -367,9 +383,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restric
         if (relu) v = v < 0.f ? 0.f : v;       // NaN propagates, like ATen's relu
         o[i] = v;
       }
-      if (ok[u]) store8(y + (size_t)(r + (long long)u * BN_RY) * C + col, o);
+      if (okc[u]) store8(y + (size_t)(r + (long long)u * BN_RY) * C + col, o);
     }
   }
+#undef BN_APPLY_ISSUE
 }
 
 template <typename T, bool FIN = false>
@@ -384,6 +401,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
   const long long r0 = base + (long long)blockIdx.y * rows_per_split;
   const long long r1 = (r0 + rows_per_split < base + M) ? r0 + rows_per_split : base + M;
   const size_t col = (size_t)blockIdx.x * 64 + (size_t)cx * 8;
+  // first rows requested before the coefficient prologue (see bn_apply_kernel)
+  Raw8<T> qx[BN_UNROLL], qg[BN_UNROLL], qy[BN_UNROLL];
+  bool ok[BN_UNROLL];
+#define BN_DX_ISSUE(rr0)                                                          \
+  {                                                                               \
+    _Pragma("unroll") for (int u = 0; u < BN_UNROLL; ++u) {                       \
+      const long long rr = (rr0) + (long long)u * BN_RY;                          \
+      ok[u] = rr < r1;                                                            \
+      const size_t off = (size_t)(ok[u] ? rr : (rr0)) * C + col;                  \
+      qx[u].load(x + off);                                                        \
+      qg[u].load(dy + off);                                                       \
+      if (relu == 1) qy[u].load(y + off);                                         \
+    }                                                                             \
+  }
+  long long r = r0 + ry;
+  if (r < r1) BN_DX_ISSUE(r)
   float k0[8], k1[8], k2[8];
   if constexpr (FIN) {
     // dgamma, dbeta (summed over the statistics groups) and this group's dx coefficients  dx = k0 * g + k1 * x + k2
@@ -437,18 +470,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
       sh[i] = beta[col + i] - mean[col + i] * sc[i];
     }
   }
-  for (long long r = r0 + ry; r < r1; r += BN_UNROLL * BN_RY) {
+  for (; r < r1; r += BN_UNROLL * BN_RY) {
     float vx[BN_UNROLL][8], vg[BN_UNROLL][8], vy[BN_UNROLL][8];
-    bool ok[BN_UNROLL];
+    bool okc[BN_UNROLL];
 #pragma unroll
     for (int u = 0; u < BN_UNROLL; ++u) {
-      const long long rr = r + (long long)u * BN_RY;
-      ok[u] = rr < r1;
-      const size_t off = (size_t)(ok[u] ? rr : r) * C + col;
-      load8(x + off, vx[u]);
-      load8(dy + off, vg[u]);
-      if (relu == 1) load8(y + off, vy[u]);
+      qx[u].unpack(vx[u]);
+      qg[u].unpack(vg[u]);
+      if (relu == 1) qy[u].unpack(vy[u]);
+      okc[u] = ok[u];
     }
+    const long long rn = r + BN_UNROLL * BN_RY;
+    if (rn < r1) BN_DX_ISSUE(rn)
 #pragma unroll
     for (int u = 0; u < BN_UNROLL; ++u) {
       float o[8], g[8];
@@ -459,15 +492,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
         if (relu == 2) g[i] = fmaf(vx[u][i], sc[i], sh[i]) <= 0.f ? 0.f : g[i];
         o[i] = fmaf(k0[i], g[i], fmaf(k1[i], vx[u][i], k2[i]));
       }
-      if (ok[u]) {
+      if (okc[u]) {
         const size_t off = (size_t)(r + (long long)u * BN_RY) * C + col;
         store8(dx + off, o);
         if (dres) store8(dres + off, g);
       }
     }
   }
+#undef BN_DX_ISSUE
 }
 
+constexpr int BN_STAT_BLOCKS = 512;      // workgroups of a statistics pass (bn_partials)
 static inline int bn_splits(long long M, int C, int target_blocks, int cap) {
   const int groups = C / 64;
   long long s = (target_blocks + groups - 1) / groups;
@@ -497,7 +532,7 @@ static void launch_bn_finalize_apply(const void* x, const void* res, const float
                                      float momentum, float eps, int relu, long long Mg, int G, int C, float* partials, int S, void* y,
                                      float* save_mean, float* save_invstd, hipStream_t st) {
   const BnRows rows = shrink_partials(partials, S, G, C, st);
-  const int S2 = bn_splits(Mg, C, 1024 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const int S2 = bn_splits(Mg, C, 512 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
   const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
   const BnFinFwd fin = {partials, rows.n, rows.stride, S, G, eps, momentum, rmean, rvar, save_mean, save_invstd};
   hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
@@ -509,7 +544,7 @@ static int run_bn_fwd(const void* x, const void* res, const float* gamma, const 
                       float momentum, float eps, int relu, long long M, int G, int C, void* y, float* save_mean, float* save_invstd,
                       float* ws, hipStream_t st) {
   const long long Mg = M / G;                      // rows per statistics group
-  const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS / G, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
   hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
                      (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C, rps, 0, ws);
@@ -521,12 +556,12 @@ template <typename T>
 static int run_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean, const float* invstd,
                       int relu, long long M, int G, int C, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
   const long long Mg = M / G;
-  const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS / G, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
   hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                      (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
   const BnRows rows = shrink_partials(ws, S_eff, G, C, st);
-  const int S2 = bn_splits(Mg, C, 1024 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const int S2 = bn_splits(Mg, C, 512 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
   const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
   const BnFinBwd fin = {ws, rows.n, rows.stride, S_eff, G, dgamma, dbeta};
   hipLaunchKernelGGL((bn_dx_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)nullptr,
@@ -540,7 +575,7 @@ static int run_bn_local_sums(int mode, const void* x, const void* dy, const void
                              const float* mean, const float* invstd, int relu, long long M, int G, int C, float* sums, float* ws,
                              hipStream_t st) {
   const long long Mg = M / G;
-  const int S = bn_splits(Mg, C, 1024 / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS / G, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
   if (mode == 0)
     hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
@@ -585,7 +620,7 @@ static bool bn_shape_ok(long long M, int G, int C) { return G >= 1 && G <= 64 &&
 
 extern "C" long long td_bn_workspace_floats(long long M, int groups, int C) {
   if (!bn_shape_ok(M, groups, C) || C % 64 != 0) return 0;
-  const int S = td::bn_splits(M / groups, C, 1024 / groups, 512);
+  const int S = td::bn_splits(M / groups, C, td::BN_STAT_BLOCKS / groups, 512);
   return ((long long)2 * S * C + (long long)3 * C) * groups;
 }
 

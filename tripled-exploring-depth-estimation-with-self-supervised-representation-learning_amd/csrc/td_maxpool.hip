@@ -67,41 +67,6 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __res
 // The backward stays the gather above: the same march needs a 5-way compare-select per (column, channel) element to find the
 // input row an output's offset points at (136 us with a register ring, 167 us with a thread-private LDS ring and ds_add_f32
 // -- both more vector-ALU work than the gather's 124 us).
-template <typename T>
-struct Raw8;
-template <>
-struct Raw8<__hip_bfloat16> {
-  unsigned w[4];
-  __device__ __forceinline__ void load(const __hip_bfloat16* p) {
-    const uint4 r = *reinterpret_cast<const uint4*>(p);
-    w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w;
-  }
-  __device__ __forceinline__ void neg_inf_unless(bool ok) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = ok ? w[i] : 0xff80ff80u;
-  }
-  __device__ __forceinline__ void unpack(float* v) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-  }
-};
-template <>
-struct Raw8<float> {
-  float w[8];
-  __device__ __forceinline__ void load(const float* p) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-  }
-  __device__ __forceinline__ void neg_inf_unless(bool ok) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = ok ? w[i] : -INFINITY;
-  }
-  __device__ __forceinline__ void unpack(float* v) const {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = w[i];
-  }
-};
-
 struct MarchCoord {
   int cv, x, n, y0, y1;
   bool live;

@@ -33,4 +33,41 @@ __device__ __forceinline__ void store8(float* p, const float* v) {
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// 8 channels as they lie in memory: lets a kernel request rows well before it converts them (the conversion of load8 would
+// otherwise sit right behind the load and wait for it)
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<__hip_bfloat16> {
+  unsigned w[4];
+  __device__ __forceinline__ void load(const __hip_bfloat16* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w;
+  }
+  __device__ __forceinline__ void neg_inf_unless(bool ok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = ok ? w[i] : 0xff80ff80u;
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <>
+struct Raw8<float> {
+  float w[8];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  }
+  __device__ __forceinline__ void neg_inf_unless(bool ok) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = ok ? w[i] : -INFINITY;
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = w[i];
+  }
+};
+
 }  // namespace td
