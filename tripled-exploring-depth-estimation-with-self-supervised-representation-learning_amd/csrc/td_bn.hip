@@ -502,7 +502,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_dx_kernel(const T* __restrict__
 #undef BN_DX_ISSUE
 }
 
-constexpr int BN_STAT_BLOCKS = 512;      // workgroups of a statistics pass (bn_partials)
+// workgroups per statistics group of a pass (bn_partials, bn_apply, bn_dx): 2048 / 1024 / 512 / 256 were measured on the training
+// step (35.7 / 35.3 / 34.9 / 35.2 ms).  Per GROUP, so a grouped call cuts its rows exactly like separate calls would (bit-equal).
+constexpr int BN_STAT_BLOCKS = 512;
 static inline int bn_splits(long long M, int C, int target_blocks, int cap) {
   const int groups = C / 64;
   long long s = (target_blocks + groups - 1) / groups;
@@ -532,7 +534,7 @@ static void launch_bn_finalize_apply(const void* x, const void* res, const float
                                      float momentum, float eps, int relu, long long Mg, int G, int C, float* partials, int S, void* y,
                                      float* save_mean, float* save_invstd, hipStream_t st) {
   const BnRows rows = shrink_partials(partials, S, G, C, st);
-  const int S2 = bn_splits(Mg, C, 512 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const int S2 = bn_splits(Mg, C, BN_STAT_BLOCKS, 4096), rps2 = bn_rows_per_split(Mg, S2);
   const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
   const BnFinFwd fin = {partials, rows.n, rows.stride, S, G, eps, momentum, rmean, rvar, save_mean, save_invstd};
   hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
@@ -544,7 +546,7 @@ static int run_bn_fwd(const void* x, const void* res, const float* gamma, const 
                       float momentum, float eps, int relu, long long M, int G, int C, void* y, float* save_mean, float* save_invstd,
                       float* ws, hipStream_t st) {
   const long long Mg = M / G;                      // rows per statistics group
-  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
   hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
                      (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C, rps, 0, ws);
@@ -556,12 +558,12 @@ template <typename T>
 static int run_bn_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean, const float* invstd,
                       int relu, long long M, int G, int C, void* dx, void* dres, float* dgamma, float* dbeta, float* ws, hipStream_t st) {
   const long long Mg = M / G;
-  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
   hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                      (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
   const BnRows rows = shrink_partials(ws, S_eff, G, C, st);
-  const int S2 = bn_splits(Mg, C, 512 / G, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const int S2 = bn_splits(Mg, C, BN_STAT_BLOCKS, 4096), rps2 = bn_rows_per_split(Mg, S2);
   const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
   const BnFinBwd fin = {ws, rows.n, rows.stride, S_eff, G, dgamma, dbeta};
   hipLaunchKernelGGL((bn_dx_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)nullptr,
@@ -575,7 +577,7 @@ static int run_bn_local_sums(int mode, const void* x, const void* dy, const void
                              const float* mean, const float* invstd, int relu, long long M, int G, int C, float* sums, float* ws,
                              hipStream_t st) {
   const long long Mg = M / G;
-  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS / G, 512), rps = bn_rows_per_split(Mg, S);
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS, 512), rps = bn_rows_per_split(Mg, S);
   const int S_eff = (int)((Mg + rps - 1) / rps);
   if (mode == 0)
     hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
@@ -620,7 +622,7 @@ static bool bn_shape_ok(long long M, int G, int C) { return G >= 1 && G <= 64 &&
 
 extern "C" long long td_bn_workspace_floats(long long M, int groups, int C) {
   if (!bn_shape_ok(M, groups, C) || C % 64 != 0) return 0;
-  const int S = td::bn_splits(M / groups, C, td::BN_STAT_BLOCKS / groups, 512);
+  const int S = td::bn_splits(M / groups, C, td::BN_STAT_BLOCKS, 512);
   return ((long long)2 * S * C + (long long)3 * C) * groups;
 }
 
