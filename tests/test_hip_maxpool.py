@@ -45,3 +45,25 @@ def test_maxpool3s2_matches_aten(dtype, N, C, H, W):
     yr.backward(go)
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     assert float((x.grad.float() - xr.grad.float()).abs().max()) <= tol * max(1.0, float(xr.grad.float().abs().max()))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (2, 64, 24, 80)])      # gather backward / scatter backward
+def test_maxpool5_nan_and_inf_follow_aten(N, C, H, W):
+    """NaN wins a window (the LAST one in row-major order takes the gradient, like ATen's scan); scattered -inf / +inf values
+    (no window is entirely -inf: ATen's index for that case depends on its memory-format kernel)."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g)
+    m = torch.rand(N, C, H, W, generator=g)
+    x[m < 0.02] = float("nan")
+    x[(m > 0.02) & (m < 0.10)] = float("-inf")
+    x[(m > 0.10) & (m < 0.12)] = float("inf")
+    x = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y, yr = ops.maxpool5(x), F.max_pool2d(xr, 5, 1, 2)
+    assert torch.equal(torch.isnan(y), torch.isnan(yr)) and torch.equal(torch.nan_to_num(y, nan=7.0), torch.nan_to_num(yr, nan=7.0))
+    go = torch.randn(N, C, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    yr.backward(go)
+    assert float((x.grad - xr.grad).abs().max()) <= 1e-5 * max(1.0, float(xr.grad.abs().max()))

@@ -163,20 +163,6 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_shrink_kernel(float* __rest
 // caller all-reduces them over the data-parallel group (2*G*C floats), and the finalize runs on the GLOBAL sums
 // with the global row count.  Same kernels either side (bn_partials / bn_apply / bn_dx).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BN_FIN_THREADS) void bn_reduce_partials_kernel(const float* __restrict__ ws, int S, int C, int G,
-                                                                           float* __restrict__ sums /* [G,C,2] */) {
-  for (int grp = 0; grp < G; ++grp) {
-    float A, B;
-    bn_sum_partials(ws + (size_t)grp * S * C * 2, S, C, blockIdx.x, A, B);
-    if (threadIdx.x < BN_FIN_CH) {
-      const size_t c = (size_t)grp * C + blockIdx.x * BN_FIN_CH + threadIdx.x;
-      sums[c * 2 + 0] = A;
-      sums[c * 2 + 1] = B;
-    }
-    __syncthreads();
-  }
-}
-
 // mean / invstd / running statistics from global (sum x, sum x^2) over `count` rows (count: device scalar, the
 // all-reduced row count, so that ranks with different batch sizes stay correct)
 __global__ __launch_bounds__(64) void bn_stats_from_sums_kernel(const float* __restrict__ sums, const float* __restrict__ count,
@@ -284,6 +270,21 @@ struct BnFinBwd {       // backward coefficients formed in bn_dx's prologue (FIN
   float* dgamma;
   float* dbeta;
 };
+
+// per-channel sums of this rank for the synchronised form: the SAME ordered sum as the prologues above (so a one-rank
+// synchronised BatchNorm equals the local one bit for bit), written out as [G, C, 2] for the all-reduce
+__global__ __launch_bounds__(BN_THREADS) void bn_tile_reduce_kernel(const float* __restrict__ ws, int S, int stride, int rows, int C, int G,
+                                                                    float* __restrict__ sums) {
+  for (int grp = 0; grp < G; ++grp) {
+    float A, B;
+    bn_tile_sums(ws + (size_t)grp * rows * C * 2, S, stride, C, blockIdx.x, A, B);
+    if (threadIdx.x < 64) {
+      const size_t c = (size_t)grp * C + (size_t)blockIdx.x * 64 + threadIdx.x;
+      sums[c * 2] = A;
+      sums[c * 2 + 1] = B;
+    }
+  }
+}
 
 template <typename T, bool FIN = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
@@ -586,7 +587,8 @@ static int run_bn_local_sums(int mode, const void* x, const void* dy, const void
   else
     hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
                        (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C / BN_FIN_CH), dim3(BN_FIN_THREADS), 0, st, (const float*)ws, S_eff, C, G, sums);
+  const BnRows rows = shrink_partials(ws, S_eff, G, C, st);
+  hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(C / 64), dim3(BN_THREADS), 0, st, (const float*)ws, rows.n, rows.stride, S_eff, C, G, sums);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 

@@ -1,8 +1,10 @@
 // 5x5 / stride 1 / pad 2 max-pooling for channels-last (NHWC) activations -- the 16 pools of the
 // CRP blocks (reference: mono/model/mono_fm_joint/layers.py:208, nn.MaxPool2d(5, 1, 2)).
-// Forward keeps a 1-byte window offset per element (ATen keeps an int64 index); backward is a
-// gather over the 25 outputs whose window contains the input element -- no atomics.
-// Tie-break and NaN handling follow ATen's max_pool2d: row-major scan, strict '>', NaN wins.
+// Forward (column march, below) keeps a 1-byte window offset dy * 5 + dx per element (ATen keeps an int64 index).
+// Backward: on the large maps an LDS scatter with column turns, on the small ones a gather over the 25 outputs whose
+// window contains the input element -- no atomics in either.
+// Tie-break and NaN handling follow ATen's max_pool2d: row-major scan, strict '>', NaN wins.  A window in which nothing
+// beats -inf sends its gradient to the centre (ATen's choice there differs between its NCHW and NHWC kernels).
 #include <hip/hip_bf16.h>
 
 #include "td_common.h"
@@ -101,11 +103,12 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_march_kernel(const T*
     okx[k] = xx >= 0 && xx < W;
     xo[k] = (size_t)(okx[k] ? xx : m.x) * C;
   }
+  const unsigned col0 = 0x22222222u;        // a window in which nothing beats -inf records its centre (offset 12)
   float hm[5][8];        // ring of row maxima, slot = (row - first row) % 5
   unsigned hd[5];        // their columns, 4 bits per channel
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
-    hd[s] = 0x22222222u;
+    hd[s] = col0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) hm[s][i] = -INFINITY;
   }
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_march_kernel(const T*
         }
         const bool oky = r >= 0 && r < H;
         float best[8];
-        unsigned col = 0x22222222u;
+        unsigned col = col0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) best[i] = -INFINITY;
 #pragma unroll
@@ -151,8 +154,9 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_fwd_march_kernel(const T*
         if (y >= m.y0) {
           float o[8];
           unsigned sel[8], sdy[8];
+          const unsigned dy0 = 2;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { o[i] = -INFINITY; sel[i] = 0x22222222u; sdy[i] = 2; }
+          for (int i = 0; i < 8; ++i) { o[i] = -INFINITY; sel[i] = col0; sdy[i] = dy0; }
 #pragma unroll
           for (int dy = 0; dy < 5; ++dy) {
             const int s = (j + 1 + dy) % 5;       // slot of row y - 2 + dy (slot j holds row y + 2)
