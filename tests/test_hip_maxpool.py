@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (1, 256, 12, 40), (3, 8, 1, 5), (2, 64, 24, 80),
+                                     (1, 128, 37, 53), (3, 64, 9, 200),                  # scatter backward: ragged tiles / strips
                                      (12, 256, 48, 160), (4, 256, 80, 256)])             # C2 / C4 stage-1 CRP block
 def test_maxpool5_matches_aten(dtype, N, C, H, W):
     import tripled_amd  # noqa: F401
