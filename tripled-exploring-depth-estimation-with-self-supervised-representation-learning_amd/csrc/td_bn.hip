@@ -4,14 +4,15 @@
 //
 // The activation tensor is a row-major [M, C] matrix (M = N*H*W pixels, C channels, C % 64 == 0).  A
 // block is 8 x 32 threads: 8 threads x 8 channels cover one 64-channel group of a row with 16-byte
-// loads, 32 rows per iteration, four iterations in flight.  Per-channel sums are two-stage and
-// deterministic: per-block partials -> one finalize block per channel group (kernel boundaries are the
-// only inter-block synchronisation; no atomics, no fences).
+// loads, 32 rows per iteration, four iterations in flight.  Per-channel sums are staged and
+// deterministic: per-block partial rows -> (more than 96 rows: shrunk in place to <= 96) -> finished in the
+// prologue of every block of the consuming kernel, all blocks forming the same ordered sum (kernel boundaries
+// are the only inter-block synchronisation; no atomics, no fences, no finalize launch).
 //
-//   forward : stats (sum x, sum x^2 partials) -> finalize (mean, 1/std, running stats)
-//             -> apply   y = relu?( (x - mean) * invstd * gamma + beta [+ residual] )
-//   backward: reduce (sum g, sum g*(x-mean) partials; g = dy * [y > 0])  -> finalize (dgamma, dbeta, dx coefficients)
-//             -> dx = gamma*invstd * (g - dbeta/M - xhat * dgamma/M),  dresidual = g
+//   forward : stats (sum x, sum x^2 partials; or the producing convolution's epilogue) [-> shrink]
+//             -> apply   prologue: mean, 1/std, running stats;  y = relu?( (x - mean) * invstd * gamma + beta [+ residual] )
+//   backward: reduce (sum g, sum g*(x-mean) partials; g = dy * [y > 0]) [-> shrink]
+//             -> dx      prologue: dgamma, dbeta, coefficients;  dx = gamma*invstd * (g - dbeta/M - xhat * dgamma/M),  dresidual = g
 #include <hip/hip_bf16.h>
 
 #include "td_common.h"
