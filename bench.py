@@ -576,7 +576,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "train imgs/sec at KITTI 192x640 bs=12/GPU",
+            "metric": "train imgs/sec at KITTI %dx%d bs=%d/GPU" % (H, W, B),      # BASELINE.json's metric on the default config (192x640, 12)
             "value": round(world * B * args.steps / elapsed, 3),
             "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
