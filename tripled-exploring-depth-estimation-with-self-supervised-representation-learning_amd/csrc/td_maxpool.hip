@@ -219,6 +219,7 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_scatter_kernel(const 
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int sl = 0; sl < MS_SLOTS; ++sl) plane[i][sl * (MS_COLS * 8) + me] = 0.f;
+  __syncthreads();                                           // the first turn already adds into other threads' entries
   const size_t nb = (size_t)n * H * W * C + (size_t)slab * 64 + (size_t)cv * 8;
   const size_t xoff = (size_t)(okx ? ox : 0) * C;
   const int rstart = y0 - 2, rend = y1 + 1;
