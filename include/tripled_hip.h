@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 2      /* 2: td_photo_fwd takes RGBX frames (td_photo_identity emits them), idloss is [B,H,W,n_src], d_up has one plane per frame */
+#define TD_ABI_VERSION 3      /* 3: fused bottleneck entry points (td_conv1x1_fwd_bnrelu, td_conv1x1_dgrad*, td_bn_*_partials); 2: td_photo_fwd takes RGBX frames (td_photo_identity emits them), idloss is [B,H,W,n_src], d_up has one plane per frame */
 #define TD_MAX_SRC 4
 
 #define TD_OK 0
@@ -294,6 +294,54 @@ int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, cons
                             float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
                             int groups, int C, float* partials, int stat_rows, void* y, float* save_mean,
                             float* save_invstd, td_stream_t stream);
+
+/*
+ * Fused forms of the bottleneck's 1x1 convolutions (round 4): the BatchNorm passes of the NEIGHBOURING layers ride on the GEMM's
+ * operand staging and epilogue instead of being separate passes over the activations.  Reference: Bottleneck.forward,
+ * mono/model/mono_fm_joint/resnet.py:66-86 (conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += identity -> relu)
+ * and what autograd derives from it.  All activations [M, C] bf16 row-major (channels-last), stride 1, channel counts % 64 == 0,
+ * `groups` stacked passes with separate statistics as td_bn_fwd.
+ *
+ * td_bn_partial_rows / td_bn_fwd_partials / td_bn_bwd_partials: the statistics passes of td_bn_fwd / td_bn_bwd on their own:
+ *   partials [groups, td_bn_partial_rows(M, groups, C), C, 2] f32 = per row range (sum x, sum x^2), resp. (sum g, sum g (x - mean))
+ *   with g = dy masked by the ReLU exactly as td_bn_bwd does.  The buffer is SCRATCH for the consumer (reduced in place).
+ * td_bn_bwd_from_partials: td_bn_bwd without its statistics pass (the sums come from td_conv1x1_dgrad_bnsums' epilogue).
+ *
+ * td_conv1x1_fwd_bnrelu: y = conv1x1(relu(bn(z)), w) where bn's batch statistics come from `in_partials` (in_rows rows per group, e.g.
+ *   from td_bn_fwd_partials; finished in the GEMM's prologue, which also writes save_mean / save_invstd [groups, K] and updates the
+ *   running statistics): conv3(relu(bn2(conv2 output))) of the bottleneck without the bn2 pass.  a_side (nullable) [M, K] receives
+ *   relu(bn(z)) (the weight gradient of this convolution needs it); stat_partials as td_conv1x1_fwd.  K <= 512.
+ * td_conv1x1_dgrad: dx[M, Cin] = dy[M, Cout] . w[Cout, Cin] (+ residual [M, Cin], added to the bf16-rounded product and rounded
+ *   again: the tensor add autograd runs behind the data gradient for the block's identity branch).  The weight is read as the
+ *   forward stores it (transposed LDS reads).
+ * td_conv1x1_dgrad_bnsums: the same GEMM whose epilogue forms the backward sums of the BatchNorm that PRODUCED this convolution's
+ *   input: out_partials [groups, td_conv1x1_stat_rows(M, groups, Cin), Cin, 2] = (sum g, sum g (z - mean)), g = dx * [bn(z) > 0],
+ *   z [M, Cin] that BatchNorm's input (conv3's data gradient + bn2's backward statistics, no pass over dx for them).
+ * td_conv1x1_dgrad_bnbwd: dx = BNbackward(g, z) . w (+ residual): the dy operand is formed while it is staged from the gradient g
+ *   [M, Cout] of relu(bn(z)) and z [M, Cout] (dz = gamma invstd (g' - mean(g') - xhat mean(g' xhat)), g' = g [bn(z) > 0]); the sums
+ *   come from in_partials (td_bn_bwd_partials), dgamma / dbeta [Cout] are written, dz_side (nullable) [M, Cout] receives dz for the
+ *   weight gradient: conv1's data gradient straight from conv2's, without the bn1 dx pass and without the residual add.  Cout <= 512.
+ */
+int td_bn_partial_rows(long long M, int groups, int C);
+int td_bn_fwd_partials(const void* x, int dtype, long long M, int groups, int C, float* partials, td_stream_t stream);
+int td_bn_bwd_partials(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C, float* partials,
+                       td_stream_t stream);
+int td_bn_bwd_from_partials(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C,
+                            float* partials, int stat_rows, void* dx, void* dresidual, float* dgamma, float* dbeta,
+                            td_stream_t stream);
+int td_conv1x1_fwd_bnrelu(const void* z, const void* w, long long M, int groups, int K, int N, float* in_partials, int in_rows,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          float* save_mean, float* save_invstd, void* a_side, void* y, float* stat_partials, td_stream_t stream);
+int td_conv1x1_dgrad(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* residual, void* dx,
+                     td_stream_t stream);
+int td_conv1x1_dgrad_bnsums(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* z,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx,
+                            float* out_partials, td_stream_t stream);
+int td_conv1x1_dgrad_bnbwd(const void* g, const void* z, const void* w, long long M, int groups, int Cout, int Cin, float* in_partials,
+                           int in_rows, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                           float* dgamma, float* dbeta, void* dz_side, const void* residual, void* dx, td_stream_t stream);
 
 /*
  * The same normalisation with statistics synchronised over the data-parallel ranks (the reference trains with

@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     import tripled_amd  # noqa: F401
     from tripled_amd import native
     lib = native.load()
-    assert lib.td_abi_version() == 2
+    assert lib.td_abi_version() == 3
     # wave tasks of 62 columns x R rows, R picked so that the tasks fill the 2048 resident wave slots in one round
     assert lib.td_photo_num_blocks(12, 192, 640) == 12 * 14 * 11      # R = 14 (even): 1848 tasks
     assert lib.td_photo_bwd_num_blocks(12, 192, 640) == 12 * 11 * 11  # R = 18: 1452 strip tasks x 2 frames = 2904 waves (3 per SIMD: 3072 slots)
@@ -59,6 +59,16 @@ def test_argument_validation_without_gpu():
     assert lib.td_fp8_quantize(None, 1, 64, None, None, None, None) == -1
     assert lib.td_join_up2_fwd(None, None, None, 1, 1, 4, 4, 8, 8, 1, None, None) == -1
     assert lib.td_bn_sync_fwd_sums(None, 1, 64, 1, 64, None, None, None) == -1
+    # round-4 entry points (fused bottleneck)
+    assert lib.td_bn_partial_rows(0, 1, 64) == 0 and lib.td_bn_partial_rows(92160, 1, 64) >= 1
+    assert lib.td_bn_partial_rows(1440, 1, 512) <= 16            # wide, short layers: the GEMM prologue finishes them directly
+    assert lib.td_bn_fwd_partials(None, 1, 64, 1, 64, None, None) == -1
+    assert lib.td_bn_bwd_partials(None, None, None, 1, None, None, None, None, 1, 64, 1, 64, None, None) == -1
+    assert lib.td_bn_bwd_from_partials(None, None, None, 1, None, None, None, None, 1, 64, 1, 64, None, 1, None, None, None, None, None) == -1
+    assert lib.td_conv1x1_fwd_bnrelu(None, None, 64, 1, 64, 64, None, 1, None, None, None, None, 0.1, 1e-5, None, None, None, None, None, None) == -1
+    assert lib.td_conv1x1_dgrad(None, None, 64, 1, 64, 64, None, None, None) == -1
+    assert lib.td_conv1x1_dgrad_bnsums(None, None, 64, 1, 64, 64, None, None, None, None, None, None, None, None) == -1
+    assert lib.td_conv1x1_dgrad_bnbwd(None, None, None, 64, 1, 64, 64, None, 1, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.td_bn_sync_bwd_dx(None, None, None, 1, None, None, None, None, None, None, None, 0, 64, 1, 64,
                                  None, None, None, None, None, None) == -1
 

@@ -176,7 +176,9 @@ def test_bottleneck_uses_the_mfma_path_and_matches_miopen():
     dispatch.reset()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         a = blk(x)
-    assert dispatch.hip_calls["td_conv1x1_fwd"] == 3 and dispatch.hip_calls["td_bn_fwd_from_partials"] == 3
+    # the fused block (round 4): conv1 + down-sample GEMMs with statistics epilogues, conv3 with bn2 + relu in its operand staging
+    assert dispatch.hip_calls["td_conv1x1_fwd"] == 2 and dispatch.hip_calls["td_conv1x1_fwd_bnrelu"] == 1 \
+        and dispatch.hip_calls["td_bn_fwd_from_partials"] == 3 and dispatch.hip_calls["td_bn_fwd_partials"] == 1
     prev = networks.FUSED_1X1_OFF
     networks.FUSED_1X1_OFF = True
     try:

@@ -184,6 +184,18 @@ def _restore(model, step, snap):
     torch.cuda.synchronize()
 
 
+def _module_slices(model, flat):
+    """index tensors into the flat master buffer, one per top-level sub-network (DepthEncoder, PoseDecoder, ...)."""
+    inner = model.module if hasattr(model, "module") else model
+    by = {}
+    for name, p in inner.named_parameters():
+        off = flat._offset_of.get(id(p))
+        if off is None:
+            continue
+        by.setdefault(name.split(".")[0], []).append(torch.arange(off, off + p.numel(), device=flat.flat_w.device))
+    return {k: torch.cat(v) for k, v in by.items()}
+
+
 @pytest.mark.parametrize("wire", ["float32", "uint8"])
 def test_runner_iteration_same_state_c2(wire):
     import tripled_amd  # noqa: F401
@@ -200,23 +212,46 @@ def test_runner_iteration_same_state_c2(wire):
         for _ in range(3):                                   # the eager iterations of the Runner's first batches
             out = it(model, dict(batch), True)
         assert it.mode is None and it.eager_iterations == 3 and it.replays == 0
+        groups = _module_slices(model, step.flat)
         for i in range(3):
             snap = _snapshot(model, step)
+            w0 = step.flat.flat_w.clone()
             out = it(model, dict(batch), True)               # call 4 captures, then replays
             torch.cuda.synchronize()
             got = ({k: float(v) for k, v in out["log_vars"].items()}, step.flat.flat_w.clone())
             assert it.mode == "one-graph" and it.replays == i + 1 and out["num_samples"] == cfg.model["imgs_per_gpu"]
+            # the reported scalars are the GRAPH's static tensors (round 3's one mismatch: after the eager iteration below
+            # had rebound step.losses, the next call reported that eager iteration's values -- DESIGN.md section 6)
+            assert all(step.losses[k].data_ptr() == it._graph_out[1][k].data_ptr() for k in step.losses)
             _restore(model, step, snap)
             step()                                           # the same iteration, eagerly, from the same state
             torch.cuda.synchronize()
             ref = {str(k): float(v) for k, v in step.losses.items()}
             ref["loss"] = float(step.loss)
+            w_e1 = step.flat.flat_w.clone()
+            _restore(model, step, snap)
+            step()                                           # and once more: the eager path's own run-to-run spread
+            torch.cuda.synchronize()
+            w_e2 = step.flat.flat_w
             assert ref.keys() == got[0].keys()
-            for k in ref:
-                assert abs(ref[k] - got[0][k]) < 1e-5 + 1e-2 * abs(ref[k]), (wire, i, k, ref[k], got[0][k])
-            d = (step.flat.flat_w - got[1]).abs()
-            print("[runner %s same-state %d] parameters: max %.2f lr, mean %.4f lr" % (wire, i, float(d.max()) / lr, float(d.mean()) / lr))
-            assert float(d.max()) <= 2.5 * lr and float(d.mean()) <= 0.25 * lr
+            bad = [(k, ref[k], got[0][k]) for k in ref if not abs(ref[k] - got[0][k]) < 1e-5 + 1e-2 * abs(ref[k])]
+            assert not bad, (wire, i, bad)                   # every entry is compared (not only the first that differs)
+            # per sub-network: the replay's parameter update against the eager one, measured against eager-vs-eager.
+            # A replay that ran a sub-network on stale inputs / stale gradients gives an update uncorrelated with the
+            # eager one (cosine ~ 0, relative difference ~ 1.4), which the former global bound (max 2.5 lr) let through.
+            worst = (1.0, "")
+            for name, idx in groups.items():
+                ug, u1, u2 = (got[1] - w0)[idx], (w_e1 - w0)[idx], (w_e2 - w0)[idx]
+                n1 = float(u1.norm())
+                assert n1 > 0, name
+                rel_ge, rel_ee = float((ug - u1).norm()) / n1, float((u2 - u1).norm()) / n1
+                cos_ge = float(torch.dot(ug, u1)) / (float(ug.norm()) * n1 + 1e-30)
+                worst = min(worst, (cos_ge, name))
+                assert rel_ge <= 1.5 * rel_ee + 0.02, (wire, i, name, rel_ge, rel_ee)
+                assert cos_ge >= 0.9 or rel_ge <= rel_ee, (wire, i, name, cos_ge, rel_ge, rel_ee)
+            d = (w_e1 - got[1]).abs()
+            print("[runner %s same-state %d] parameters: max %.2f lr, mean %.4f lr; worst sub-network cosine %.4f (%s)"
+                  % (wire, i, float(d.max()) / lr, float(d.mean()) / lr, worst[0], worst[1]))
         # a ragged batch takes the eager iteration and leaves the graph usable
         half = {k: v[:6].clone() for k, v in batch.items()}
         out = it(model, half, True)

@@ -56,3 +56,67 @@ def test_only_adam_configs_are_accepted():
     cfg = ConfigDict(model=model.opt, optimizer=dict(type="SGD", lr=1e-2), optimizer_config=dict(grad_clip=None))
     with pytest.raises(ValueError):
         TrainStep(model, cfg, step.batch, None)
+
+
+def test_list_valued_losses_reduce_like_the_reference():
+    """reference: mono/apis/trainer.py:39-47 -- tensor -> mean, list -> sum of means, anything else -> TypeError."""
+    from tripled_amd.step import reduce_loss
+    a, b = torch.tensor([1.0, 3.0]), torch.tensor([[2.0], [6.0]])
+    assert float(reduce_loss("t", a)) == 2.0
+    assert float(reduce_loss("l", [a, b])) == 6.0
+    with pytest.raises(TypeError, match="bad"):
+        reduce_loss("bad", 3.0)
+
+
+def test_runner_iteration_reports_the_graphs_outputs_after_an_eager_iteration():
+    """Root cause of the one graph-vs-eager mismatch of round 3: an eager ``step()`` between two
+    replays (a ragged batch; the same-state parity test) rebinds ``step.loss`` / ``step.losses`` to the eager iteration's
+    tensors; a replay refreshes only the graph's STATIC tensors, so ``RunnerIteration`` must report those and not whatever
+    ``step.losses`` points at.  Runs on the host with a stand-in for the captured graph."""
+    from collections import OrderedDict
+    from tripled_amd.step import RunnerIteration
+
+    class FakeStep:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.loss, self.losses, self.batch = None, {}, None
+            self.calls = 0
+
+        def __call__(self):                         # an eager iteration: NEW tensors, like TrainStep.forward_backward
+            self.calls += 1
+            self.losses = OrderedDict(a=torch.tensor(100.0 + self.calls))
+            self.loss = torch.tensor(100.0 + self.calls)
+
+        def check_finite(self, what=""):
+            return float(self.loss)
+
+    step = FakeStep()
+    it = RunnerIteration(step, stage=lambda d: d, eager_processor=None, warmup_iters=1)
+    static_losses, static_loss = OrderedDict(a=torch.tensor(0.0)), torch.tensor(0.0)
+
+    def replay():                                   # a graph replay: writes into the static tensors, rebinds nothing
+        static_losses["a"].add_(1.0)
+        static_loss.add_(1.0)
+
+    it.mode, it.graphed, it._graph_out = "one-graph", replay, (static_loss, static_losses)
+    it.static = {"K": torch.zeros(2, 4, 4)}
+    it.signature = it._sig(it.static)
+    it.seen = 1
+
+    class Model:
+        def train(self):
+            pass
+
+    data = {"K": torch.zeros(2, 4, 4)}
+    out = it(Model(), dict(data), True)
+    assert float(out["log_vars"]["a"]) == 1.0
+    step()                                          # eager iteration in between (rebinds step.losses)
+    assert float(step.losses["a"]) == 101.0
+    out = it(Model(), dict(data), True)
+    assert float(out["log_vars"]["a"]) == 2.0 and float(out["loss"]) == 2.0     # the replay's value, not 101
+    ragged = {"K": torch.zeros(1, 4, 4)}
+    out = it(Model(), ragged, True)                 # another shape: eager on that batch
+    assert float(out["log_vars"]["a"]) == 102.0 and it.eager_iterations == 1
+    out = it(Model(), dict(data), True)
+    assert float(out["log_vars"]["a"]) == 3.0

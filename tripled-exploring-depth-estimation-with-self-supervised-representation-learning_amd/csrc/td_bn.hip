@@ -522,12 +522,14 @@ static inline int bn_rows_per_split(long long M, int S) {
 }
 
 // the partial rows a consumer prologue sums: all S of them, or -- after bn_shrink_kernel -- every Sq-th
-struct BnRows { int n, stride; };
-static BnRows shrink_partials(float* partials, int S, int G, int C, hipStream_t st) {
-  if (S <= BN_PRO_MAX_S) return {S, 1};
-  const int Sq = (S + BN_PRO_MAX_S - 1) / BN_PRO_MAX_S, Q = (S + Sq - 1) / Sq;
+BnRows bn_shrink_partials_to(float* partials, int S, int G, int C, int max_rows, hipStream_t st) {
+  if (S <= max_rows) return {S, 1};
+  const int Sq = (S + max_rows - 1) / max_rows, Q = (S + Sq - 1) / Sq;
   hipLaunchKernelGGL(bn_shrink_kernel, dim3(C / BN_FIN_CH, Q, G), dim3(BN_FIN_THREADS), 0, st, partials, S, C, Sq);
   return {Q, Sq};
+}
+static BnRows shrink_partials(float* partials, int S, int G, int C, hipStream_t st) {
+  return bn_shrink_partials_to(partials, S, G, C, BN_PRO_MAX_S, st);
 }
 
 // statistics (in the apply kernel's prologue) + apply, from partial sums; `partials` is reduced in place when S > BN_PRO_MAX_S
@@ -541,6 +543,49 @@ static void launch_bn_finalize_apply(const void* x, const void* res, const float
   const BnFinFwd fin = {partials, rows.n, rows.stride, S, G, eps, momentum, rmean, rvar, save_mean, save_invstd};
   hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)res, gamma, beta,
                      (const float*)nullptr, (const float*)nullptr, Mg, C, rps2, relu, (T*)y, fin);
+}
+
+// row splits of a statistics pass whose partial rows a GEMM prologue finishes (td_conv1x1_fwd_bnrelu / td_conv1x1_dgrad_bnbwd: at
+// most 16 rows per block there): wide, short layers are cut into 16 ranges directly (no shrink launch); the others as every pass
+static inline int bn_stat_splits(long long Mg, int C) {
+  const int S = bn_splits(Mg, C, BN_STAT_BLOCKS, 512);
+  if (S > 16 && (C / 64) * 16 >= 128) return bn_splits(Mg, C, (C / 64) * 16, 16);
+  return S;
+}
+static inline int bn_stat_rows(long long Mg, int C) {
+  const int S = bn_stat_splits(Mg, C), rps = bn_rows_per_split(Mg, S);
+  return (int)((Mg + rps - 1) / rps);
+}
+
+template <typename T>
+static int run_bn_partials(int mode, const void* x, const void* dy, const void* y, const float* gamma, const float* beta, const float* mean,
+                           const float* invstd, int relu, long long M, int G, int C, float* ws, hipStream_t st) {
+  const long long Mg = M / G;
+  const int S = bn_stat_splits(Mg, C), rps = bn_rows_per_split(Mg, S);
+  const int S_eff = (int)((Mg + rps - 1) / rps);
+  if (mode == 0)
+    hipLaunchKernelGGL((bn_partials_kernel<T, 0>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)nullptr,
+                       (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mg, C,
+                       rps, 0, ws);
+  else
+    hipLaunchKernelGGL((bn_partials_kernel<T, 1>), dim3(C / 64, S_eff, G), dim3(BN_THREADS), 0, st, (const T*)x, (const T*)dy,
+                       (const T*)y, mean, invstd, gamma, beta, Mg, C, rps, relu, ws);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+// dx (+ dgamma, dbeta) from backward partial sums formed elsewhere (a GEMM epilogue): shrink when needed, finish in bn_dx's prologue
+template <typename T>
+static int run_bn_dx_from_partials(const void* dy, const void* x, const void* y, const float* gamma, const float* beta, const float* mean,
+                                   const float* invstd, int relu, long long M, int G, int C, float* partials, int S, void* dx, void* dres,
+                                   float* dgamma, float* dbeta, hipStream_t st) {
+  const long long Mg = M / G;
+  const BnRows rows = shrink_partials(partials, S, G, C, st);
+  const int S2 = bn_splits(Mg, C, BN_STAT_BLOCKS, 4096), rps2 = bn_rows_per_split(Mg, S2);
+  const dim3 grid(C / 64, (unsigned)((Mg + rps2 - 1) / rps2), G);
+  const BnFinBwd fin = {partials, rows.n, rows.stride, S, G, dgamma, dbeta};
+  hipLaunchKernelGGL((bn_dx_kernel<T, true>), grid, dim3(BN_THREADS), 0, st, (const T*)dy, (const T*)x, (const T*)y, (const float*)nullptr,
+                     mean, invstd, gamma, beta, Mg, C, rps2, relu, (T*)dx, (T*)dres, fin);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
 
 template <typename T>
@@ -683,6 +728,55 @@ extern "C" int td_bn_fwd_from_partials(const void* x, const void* residual, int 
     td::launch_bn_finalize_apply<float>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, Mg, groups, C, partials, stat_rows,
                                         y, save_mean, save_invstd, st);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+// ---- the statistics passes on their own (their partial rows are finished by a GEMM prologue or by td_bn_bwd_from_partials) ----
+extern "C" int td_bn_partial_rows(long long M, int groups, int C) {
+  if (!bn_shape_ok(M, groups, C) || C % 64 != 0) return 0;
+  return td::bn_stat_rows(M / groups, C);
+}
+
+extern "C" int td_bn_fwd_partials(const void* x, int dtype, long long M, int groups, int C, float* partials, td_stream_t stream) {
+  if (!x || !partials || !bn_shape_ok(M, groups, C)) return TD_ERR_BAD_ARG;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_partials<__hip_bfloat16>(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, M, groups, C, partials, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_partials<float>(0, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, M, groups, C, partials, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_bn_bwd_partials(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta,
+                                  const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C,
+                                  float* partials, td_stream_t stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !partials || !bn_shape_ok(M, groups, C)) return TD_ERR_BAD_ARG;
+  if (relu < 0 || relu > 1 || (relu && !y && !beta)) return TD_ERR_BAD_ARG;
+  if (relu && !y) relu = 2;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_partials<__hip_bfloat16>(1, x, dy, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, partials, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_partials<float>(1, x, dy, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, partials, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_bn_bwd_from_partials(const void* dy, const void* x, const void* y, int dtype, const float* gamma, const float* beta,
+                                       const float* save_mean, const float* save_invstd, int relu, long long M, int groups, int C,
+                                       float* partials, int stat_rows, void* dx, void* dresidual, float* dgamma, float* dbeta,
+                                       td_stream_t stream) {
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !partials || stat_rows < 1 || !bn_shape_ok(M, groups, C))
+    return TD_ERR_BAD_ARG;
+  if (relu < 0 || relu > 1) return TD_ERR_BAD_ARG;
+  if (relu && !y && (!beta || dresidual)) return TD_ERR_BAD_ARG;
+  if (relu && !y) relu = 2;
+  if (C % 64 != 0 || M * (long long)C >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16)
+    return td::run_bn_dx_from_partials<__hip_bfloat16>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, partials, stat_rows,
+                                                       dx, dresidual, dgamma, dbeta, (hipStream_t)stream);
+  if (dtype == TD_DTYPE_F32)
+    return td::run_bn_dx_from_partials<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, M, groups, C, partials, stat_rows, dx,
+                                              dresidual, dgamma, dbeta, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
 }
 
 // ---- synchronised (cross-rank) statistics: local sums -> [caller: all-reduce] -> apply / dx --------------------

@@ -18,6 +18,9 @@ namespace td {
 
 int record_launch_error(hipError_t e, const char* what);
 
+// the partial rows a consumer prologue sums: rows 0, stride, 2 stride, ... (n of them)
+struct BnRows { int n, stride; };
+
 __device__ __forceinline__ int reflect1(int i, int n) {
   // ReflectionPad2d(1) index map (-1 -> 1, n -> n-2), then clamped so that positions
   // outside the padded domain (never consumed) still address valid memory.

@@ -35,13 +35,91 @@ __device__ __forceinline__ long long cv_src_row(long long m, const ConvRows& g) 
   return b * g.HiWi + (long long)ho * g.stride * g.Wi + (long long)wo * g.stride;
 }
 
-template <int BM, int BN>
+// ---- fused forms (round 4) -------------------------------------------------------------------------------------------
+// The same GEMM serves the data gradient (BT: the weight is read as it lies, [reduction][N], through transposed LDS reads) and
+// takes BatchNorm work of the NEIGHBOURING layers on both ends, so that the separate passes over the activations disappear
+// (reference: Bottleneck.forward, mono/model/mono_fm_joint/resnet.py:66-86, and its autograd):
+//   PRO 1  A = relu(bn(z)): conv3's input straight from conv2's raw output; the statistics are finished from <= 16 partial rows in
+//          the prologue of every block (same ordered sum everywhere), block 0 writes save_mean / save_invstd / running statistics
+//   PRO 2  A = the BatchNorm-backward of (g, z): dz = k0 g [fma(z, sc, sh) > 0] + k1 z + k2 -- conv1's data gradient straight
+//          from conv2's data gradient; coefficients finished from the backward partial rows in the prologue, block 0 writes
+//          dgamma / dbeta
+//   a_side the transformed A operand is also written out by the n-tile-0 blocks (the weight gradient needs it)
+//   EPI    td_conv_tile.h: residual add / backward sums of the next BatchNorm in backward order
+struct CvFuse {
+  const __hip_bfloat16* a2;       // PRO 2: z (x is g)
+  const float* part;              // PRO 1: [G, part_rows, K, 2] (sum z, sum z^2); PRO 2: (sum g, sum g (z - mean)); rows 0, stride, ...
+  int part_S, part_stride, part_rows;
+  const float* gamma;             // [K]
+  const float* beta;              // [K]
+  float* mean;                    // [G, K]  PRO 1: written; PRO 2: read
+  float* invstd;                  // [G, K]
+  float* rmean;                   // PRO 1: running statistics (nullable)
+  float* rvar;
+  float momentum, eps;
+  float* dgamma;                  // PRO 2: [K]
+  float* dbeta;
+  __hip_bfloat16* a_side;         // [M, K] (nullable)
+  int G;
+  CvEpi ep;
+};
+
+constexpr int CV_PRO_MAX_K = 512;        // prologue coefficients live in LDS: 5 floats per reduction channel
+constexpr int CV_PRO_MAX_S = 16;         // partial rows a block finishes itself
+
+__device__ __forceinline__ uint4 cv_pro1(uint4 x, const float* sc, const float* sh) {
+  const unsigned w[4] = {x.x, x.y, x.z, x.w};
+  unsigned o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v0 = fmaf(bf2f((unsigned short)(w[e] & 0xffff)), sc[2 * e], sh[2 * e]);
+    float v1 = fmaf(bf2f((unsigned short)(w[e] >> 16)), sc[2 * e + 1], sh[2 * e + 1]);
+    v0 = v0 < 0.f ? 0.f : v0;
+    v1 = v1 < 0.f ? 0.f : v1;
+    o[e] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ uint4 cv_pro2(uint4 g, uint4 z, const float* k0, const float* k1, const float* k2, const float* sc,
+                                         const float* sh) {
+  const unsigned gw[4] = {g.x, g.y, g.z, g.w}, zw[4] = {z.x, z.y, z.z, z.w};
+  unsigned o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float z0 = bf2f((unsigned short)(zw[e] & 0xffff)), z1 = bf2f((unsigned short)(zw[e] >> 16));
+    float g0 = bf2f((unsigned short)(gw[e] & 0xffff)), g1 = bf2f((unsigned short)(gw[e] >> 16));
+    g0 = fmaf(z0, sc[2 * e], sh[2 * e]) <= 0.f ? 0.f : g0;                 // threshold_backward on the recomputed pre-activation
+    g1 = fmaf(z1, sc[2 * e + 1], sh[2 * e + 1]) <= 0.f ? 0.f : g1;
+    const float v0 = fmaf(k0[2 * e], g0, fmaf(k1[2 * e], z0, k2[2 * e]));
+    const float v1 = fmaf(k0[2 * e + 1], g1, fmaf(k1[2 * e + 1], z1, k2[2 * e + 1]));
+    o[e] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// (A, B) = ordered sum of the partial rows 0, stride, ... (S of them) of channel c
+__device__ __forceinline__ void cv_sum_rows(const float* __restrict__ part, int S, int stride, int K, int c, float& A, float& B) {
+  float2 v[CV_PRO_MAX_S];
+#pragma unroll
+  for (int u = 0; u < CV_PRO_MAX_S; ++u)
+    v[u] = *reinterpret_cast<const float2*>(part + ((size_t)(u < S ? u : 0) * stride * K + c) * 2);
+  A = 0.f;
+  B = 0.f;
+#pragma unroll
+  for (int u = 0; u < CV_PRO_MAX_S; ++u) {
+    A += u < S ? v[u].x : 0.f;
+    B += u < S ? v[u].y : 0.f;
+  }
+}
+
+template <int BM, int BN, bool BT, int PRO, int EPI>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w, __hip_bfloat16* __restrict__ y,
-    float* __restrict__ ws, long long Mg, int K, int N, int tiles_per_group, int total_blocks, ConvRows geom) {
-  using T = CvTile<BM, BN>;
+    float* __restrict__ ws, long long Mg, int K, int N, int tiles_per_group, int total_blocks, ConvRows geom, CvFuse fz) {
+  using T = CvTile<BM, BN, BT>;
   constexpr int A_BYTES = T::A_BYTES, STAGE = T::STAGE, TN = T::TN, TM = T::TM;
   __shared__ __attribute__((aligned(16))) unsigned char lds[T::LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) float s_pro[PRO == 0 ? 4 : (PRO == 1 ? 2 : 5) * CV_PRO_MAX_K];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, h = lane >> 5;
@@ -58,36 +136,91 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
   // arrays: hipcc otherwise parks the staging registers in scratch / promotes them to LDS.
   const int lc = tid & 7, lr = tid >> 3;
   constexpr int NA = BM / 32, NB = BN / 32;
-  auto a_ptr = [&](int i) {
+  auto a_off = [&](int i) {
     int r = lr + 32 * i;
     r = r < rows_valid ? r : rows_valid - 1;       // rows past the group's end: a valid row, never stored or summed
-    return x + cv_src_row(row0 + r, geom) * (long long)K + lc * 8;
+    return cv_src_row(row0 + r, geom) * (long long)K + lc * 8;
   };
-  const __hip_bfloat16 *pa0 = a_ptr(0), *pa1 = a_ptr(1), *pa2 = NA > 2 ? a_ptr(2) : pa0, *pa3 = NA > 2 ? a_ptr(3) : pa0;
-  const __hip_bfloat16* pb0 = w + (long long)(n0 + lr) * K + lc * 8;
-  const __hip_bfloat16 *pb1 = pb0 + 32ll * K, *pb2 = pb0 + (NB > 2 ? 64ll : 0ll) * K, *pb3 = pb0 + (NB > 2 ? 96ll : 0ll) * K;
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const long long oa0 = a_off(0), oa1 = a_off(1), oa2 = NA > 2 ? a_off(2) : oa0, oa3 = NA > 2 ? a_off(3) : oa0;
+  const __hip_bfloat16 *pa0 = x + oa0, *pa1 = x + oa1, *pa2 = x + oa2, *pa3 = x + oa3;
+  // weight tile: [BN rows][64 k] chunks (t & 7) of rows (t >> 3) + 32 i -- or, BT, [64 reduction rows][BN columns]: chunk t % (BN / 8)
+  // of rows t / (BN / 8) + (256 / (BN / 8)) i; either way NB 16-byte chunks per thread and stage
+  constexpr int CPR = BN / 8, RPP = CV_THREADS / CPR;
+  const int bc = tid % CPR, br = tid / CPR;
+  const __hip_bfloat16* pb0 = BT ? w + (long long)br * N + n0 + bc * 8 : w + (long long)(n0 + lr) * K + lc * 8;
+  const long long bstep = BT ? (long long)RPP * N : 32ll * K;
+  const __hip_bfloat16 *pb1 = pb0 + bstep, *pb2 = pb0 + (NB > 2 ? 2 : 0) * bstep, *pb3 = pb0 + (NB > 2 ? 3 : 0) * bstep;
+  const long long bkt = BT ? (long long)CV_BK * N : (long long)CV_BK;     // weight pointer advance per K stage
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rz0, rz1, rz2, rz3;
   ra2 = ra3 = rb2 = rb3 = make_uint4(0, 0, 0, 0);
+  rz0 = rz1 = rz2 = rz3 = make_uint4(0, 0, 0, 0);
 #define CV_LD(p, kt) (*reinterpret_cast<const uint4*>((p) + (kt) * CV_BK))
+#define CV_LDB(p, kt) (*reinterpret_cast<const uint4*>((p) + (kt) * bkt))
 #define CV_LOAD_GLOBAL(kt)                                     \
   {                                                            \
     ra0 = CV_LD(pa0, kt);                                      \
     ra1 = CV_LD(pa1, kt);                                      \
     if (NA > 2) { ra2 = CV_LD(pa2, kt); ra3 = CV_LD(pa3, kt); } \
-    rb0 = CV_LD(pb0, kt);                                      \
-    rb1 = CV_LD(pb1, kt);                                      \
-    if (NB > 2) { rb2 = CV_LD(pb2, kt); rb3 = CV_LD(pb3, kt); } \
+    if constexpr (PRO == 2) {                                  \
+      rz0 = CV_LD(fz.a2 + oa0, kt);                            \
+      rz1 = CV_LD(fz.a2 + oa1, kt);                            \
+      if (NA > 2) { rz2 = CV_LD(fz.a2 + oa2, kt); rz3 = CV_LD(fz.a2 + oa3, kt); } \
+    }                                                          \
+    rb0 = CV_LDB(pb0, kt);                                     \
+    rb1 = CV_LDB(pb1, kt);                                     \
+    if (NB > 2) { rb2 = CV_LDB(pb2, kt); rb3 = CV_LDB(pb3, kt); } \
   }
 #define CV_ST(base, i, v) (*reinterpret_cast<uint4*>((base) + cv_swz(lr + 32 * (i), lc)) = (v))
-#define CV_WRITE_LDS(stage)                                              \
+#define CV_STB(base, i, v)                                                                              \
+  {                                                                                                     \
+    if constexpr (BT) *reinterpret_cast<uint4*>((base) + (br + RPP * (i)) * T::PITCH_T + bc * 16) = (v); \
+    else CV_ST(base, i, v);                                                                             \
+  }
+  // the A operand passes through the prologue transform on its way into LDS (and, n-tile 0, out to a_side)
+#define CV_PRO_A(kt)                                                                                    \
+  {                                                                                                     \
+    if constexpr (PRO != 0) {                                                                           \
+      const int c0_ = (kt) * CV_BK + lc * 8;                                                            \
+      float q0[8], q1[8], q2[8], q3[8], q4[8];                                                          \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+        q0[e] = s_pro[0 * CV_PRO_MAX_K + c0_ + e];                                                      \
+        q1[e] = s_pro[1 * CV_PRO_MAX_K + c0_ + e];                                                      \
+        if constexpr (PRO == 2) {                                                                       \
+          q2[e] = s_pro[2 * CV_PRO_MAX_K + c0_ + e];                                                    \
+          q3[e] = s_pro[3 * CV_PRO_MAX_K + c0_ + e];                                                    \
+          q4[e] = s_pro[4 * CV_PRO_MAX_K + c0_ + e];                                                    \
+        }                                                                                               \
+      }                                                                                                 \
+      if constexpr (PRO == 1) {                                                                         \
+        ra0 = cv_pro1(ra0, q0, q1);                                                                     \
+        ra1 = cv_pro1(ra1, q0, q1);                                                                     \
+        if (NA > 2) { ra2 = cv_pro1(ra2, q0, q1); ra3 = cv_pro1(ra3, q0, q1); }                         \
+      } else {                                                                                          \
+        ra0 = cv_pro2(ra0, rz0, q0, q1, q2, q3, q4);                                                    \
+        ra1 = cv_pro2(ra1, rz1, q0, q1, q2, q3, q4);                                                    \
+        if (NA > 2) { ra2 = cv_pro2(ra2, rz2, q0, q1, q2, q3, q4); ra3 = cv_pro2(ra3, rz3, q0, q1, q2, q3, q4); } \
+      }                                                                                                 \
+      if (fz.a_side && nt == 0) {                                                                       \
+        __hip_bfloat16* sd_ = fz.a_side + (row0 + lr) * (long long)K + c0_;                             \
+        if (lr < rows_valid) *reinterpret_cast<uint4*>(sd_) = ra0;                                      \
+        if (lr + 32 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 32ll * K) = ra1;                      \
+        if (NA > 2) {                                                                                   \
+          if (lr + 64 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 64ll * K) = ra2;                    \
+          if (lr + 96 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 96ll * K) = ra3;                    \
+        }                                                                                               \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+#define CV_WRITE_LDS(stage, kt)                                          \
   {                                                                      \
     unsigned char* base_ = lds + (stage) * STAGE;                        \
+    CV_PRO_A(kt)                                                         \
     CV_ST(base_, 0, ra0);                                                \
     CV_ST(base_, 1, ra1);                                                \
     if (NA > 2) { CV_ST(base_, 2, ra2); CV_ST(base_, 3, ra3); }          \
-    CV_ST(base_ + A_BYTES, 0, rb0);                                      \
-    CV_ST(base_ + A_BYTES, 1, rb1);                                      \
-    if (NB > 2) { CV_ST(base_ + A_BYTES, 2, rb2); CV_ST(base_ + A_BYTES, 3, rb3); } \
+    CV_STB(base_ + A_BYTES, 0, rb0);                                     \
+    CV_STB(base_ + A_BYTES, 1, rb1);                                     \
+    if (NB > 2) { CV_STB(base_ + A_BYTES, 2, rb2); CV_STB(base_ + A_BYTES, 3, rb3); } \
   }
 
   CvAcc<BM, BN> acc;
@@ -99,26 +232,98 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
       for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
 
   const int nk = K / CV_BK;
-  CV_LOAD_GLOBAL(0)
-  CV_WRITE_LDS(0)
+  CV_LOAD_GLOBAL(0)                       // the first tiles are on their way while the prologue finishes the statistics
+
+  if constexpr (PRO == 1) {
+    const float* part = fz.part + (size_t)grp * fz.part_rows * K * 2;
+    const bool first = (s == 0 && nt == 0);
+    for (int c = tid; c < K; c += CV_THREADS) {
+      float A, B;
+      cv_sum_rows(part, fz.part_S, fz.part_stride, K, c, A, B);
+      const double m = (double)A / (double)Mg;
+      double var = (double)B / (double)Mg - m * m;      // biased variance, formed in double (as bn_apply_kernel)
+      var = var > 0.0 ? var : 0.0;
+      const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)fz.eps));
+      const float scv = fz.gamma[c] * isf;
+      s_pro[c] = scv;
+      s_pro[CV_PRO_MAX_K + c] = fz.beta[c] - mf * scv;
+      if (first) {
+        fz.mean[(size_t)grp * K + c] = mf;
+        fz.invstd[(size_t)grp * K + c] = isf;
+      }
+      if (fz.rmean && first && grp == 0) {             // one momentum update per group, in order (G separate calls)
+        double rm = fz.rmean[c], rv = fz.rvar[c];
+        for (int g2 = 0; g2 < fz.G; ++g2) {
+          float A2 = A, B2 = B;
+          if (g2 != 0) cv_sum_rows(fz.part + (size_t)g2 * fz.part_rows * K * 2, fz.part_S, fz.part_stride, K, c, A2, B2);
+          const double m2 = (double)A2 / (double)Mg;
+          double v2 = (double)B2 / (double)Mg - m2 * m2;
+          v2 = v2 > 0.0 ? v2 : 0.0;
+          const double unbiased = Mg > 1 ? v2 * ((double)Mg / (double)(Mg - 1)) : v2;
+          rm = (double)(float)((1.0 - fz.momentum) * rm + fz.momentum * m2);
+          rv = (double)(float)((1.0 - fz.momentum) * rv + fz.momentum * unbiased);
+        }
+        fz.rmean[c] = (float)rm;
+        fz.rvar[c] = (float)rv;
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (PRO == 2) {
+    const float* part = fz.part + (size_t)grp * fz.part_rows * K * 2;
+    const float inv_m = 1.f / (float)Mg;
+    const bool first = (s == 0 && nt == 0 && grp == 0);
+    for (int c = tid; c < K; c += CV_THREADS) {
+      float A, B;
+      cv_sum_rows(part, fz.part_S, fz.part_stride, K, c, A, B);
+      const float is = fz.invstd[(size_t)grp * K + c], mu = fz.mean[(size_t)grp * K + c];
+      const float dg = B * is;                     // sum g * xhat
+      const float c0 = fz.gamma[c] * is;
+      const float c1 = -c0 * is * dg * inv_m;      // multiplies (z - mean)
+      s_pro[0 * CV_PRO_MAX_K + c] = c0;
+      s_pro[1 * CV_PRO_MAX_K + c] = c1;
+      s_pro[2 * CV_PRO_MAX_K + c] = -c0 * A * inv_m - c1 * mu;
+      s_pro[3 * CV_PRO_MAX_K + c] = c0;            // gamma * invstd: the forward's scale
+      s_pro[4 * CV_PRO_MAX_K + c] = fz.beta[c] - mu * c0;
+      if (first) {
+        float dg_tot = 0.f, db_tot = 0.f;
+        for (int g2 = 0; g2 < fz.G; ++g2) {
+          float A2 = A, B2 = B;
+          if (g2 != 0) cv_sum_rows(fz.part + (size_t)g2 * fz.part_rows * K * 2, fz.part_S, fz.part_stride, K, c, A2, B2);
+          dg_tot += B2 * fz.invstd[(size_t)g2 * K + c];
+          db_tot += A2;
+        }
+        fz.dgamma[c] = dg_tot;
+        fz.dbeta[c] = db_tot;
+      }
+    }
+    __syncthreads();
+  }
+
+  CV_WRITE_LDS(0, 0)
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) CV_LOAD_GLOBAL(kt + 1)
     const unsigned char* sa = lds + (kt & 1) * STAGE;
     const unsigned char* sb = sa + A_BYTES;
-    cv_stage_mfma<BM, BN>(acc, sa, sb, wm, wn, l31, h);
-    if (more) CV_WRITE_LDS((kt + 1) & 1)
+    cv_stage_mfma<BM, BN, BT>(acc, sa, sb, wm, wn, l31, h);
+    if (more) CV_WRITE_LDS((kt + 1) & 1, kt + 1)
     __syncthreads();
   }
 
-  cv_epilogue<BM, BN>(acc, lds, y, ws, row0, rows_valid, n0, N, (long long)grp * tiles_per_group + s, tid, wm, wn, l31, h);
+  CvEpi ep = fz.ep;
+  if constexpr (EPI == 2) { ep.mean += (size_t)grp * N; ep.invstd += (size_t)grp * N; }
+  cv_epilogue<BM, BN, EPI>(acc, lds, y, ws, row0, rows_valid, n0, N, (long long)grp * tiles_per_group + s, tid, wm, wn, l31, h, ep);
 }
 
 #undef CV_LOAD_GLOBAL
 #undef CV_WRITE_LDS
+#undef CV_PRO_A
 #undef CV_LD
+#undef CV_LDB
 #undef CV_ST
+#undef CV_STB
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same convolution:  dW[n, k] = sum_m dY[m, n] * X[src(m), k]   (reference: autograd of
@@ -267,14 +472,29 @@ static inline int wg_splits(long long M, int K, int N) {
   return (int)(p < 1 ? 1 : p);
 }
 
-template <int BM, int BN>
-static int cv_launch(const void* x, const void* w, void* y, float* ws, long long Mg, int G, int K, int N, ConvRows geom, hipStream_t st) {
+template <int BM, int BN, bool BT = false, int PRO = 0, int EPI = 0>
+static int cv_launch(const void* x, const void* w, void* y, float* ws, long long Mg, int G, int K, int N, ConvRows geom, hipStream_t st,
+                     const CvFuse& fz = CvFuse{}) {
   const int tpg = (int)((Mg + BM - 1) / BM);
   const long long nblk = (long long)G * tpg * (N / BN);
   if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv1x1_mfma_kernel<BM, BN>), dim3((unsigned)nblk), dim3(CV_THREADS), 0, st, (const __hip_bfloat16*)x,
-                     (const __hip_bfloat16*)w, (__hip_bfloat16*)y, ws, Mg, K, N, tpg, (int)nblk, geom);
+  hipLaunchKernelGGL((conv1x1_mfma_kernel<BM, BN, BT, PRO, EPI>), dim3((unsigned)nblk), dim3(CV_THREADS), 0, st, (const __hip_bfloat16*)x,
+                     (const __hip_bfloat16*)w, (__hip_bfloat16*)y, ws, Mg, K, N, tpg, (int)nblk, geom, fz);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+// tile choice as the plain forward; one instantiation set per fused form
+template <bool BT, int PRO, int EPI>
+static int cv_dispatch(const void* x, const void* w, void* y, float* ws, long long M, int G, int K, int N, ConvRows geom, hipStream_t st,
+                       const CvFuse& fz) {
+  const long long Mg = M / G;
+  ConvTile t = cv_pick_tile(Mg, G, N);
+  if constexpr (PRO == 2) {      // its prologue coefficients + the transposed weight stage leave no room for two 128 x 128 blocks per CU
+    if (t.bm == 128 && t.bn == 128) t.bn = 64;
+  } else
+    if (t.bm == 128 && t.bn == 128) return cv_launch<128, 128, BT, PRO, EPI>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+  if (t.bm == 128 && t.bn == 64) return cv_launch<128, 64, BT, PRO, EPI>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+  return cv_launch<64, 64, BT, PRO, EPI>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
 }
 
 }  // namespace td
@@ -300,12 +520,72 @@ extern "C" int td_conv1x1_fwd(const void* x, const void* w, long long M, int gro
     geom = {Wo, Ho * Wo, Wi, Hi * Wi, stride};
   }
   if (M * (long long)(K > N ? K : N) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
-  const long long Mg = M / groups;
-  const td::ConvTile t = td::cv_pick_tile(Mg, groups, N);
+  return td::cv_dispatch<false, 0, 0>(x, w, y, stat_partials, M, groups, K, N, geom, (hipStream_t)stream, td::CvFuse{});
+}
+
+// partial rows (any producer) reduced in place to at most CV_PRO_MAX_S rows for a GEMM prologue; returns (rows, stride)
+namespace td {
+BnRows bn_shrink_partials_to(float* partials, int S, int G, int C, int max_rows, hipStream_t st);   // td_bn.hip
+}
+
+extern "C" int td_conv1x1_fwd_bnrelu(const void* z, const void* w, long long M, int groups, int K, int N, float* in_partials,
+                                     int in_rows, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, float* save_mean, float* save_invstd, void* a_side, void* y,
+                                     float* stat_partials, td_stream_t stream) {
+  if (!z || !w || !y || !in_partials || in_rows < 1 || !gamma || !beta || !save_mean || !save_invstd || !cv_shape_ok(M, groups, K, N))
+    return TD_ERR_BAD_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TD_ERR_BAD_ARG;
+  if (K > td::CV_PRO_MAX_K || M * (long long)(K > N ? K : N) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (t.bm == 128 && t.bn == 128) return td::cv_launch<128, 128>(x, w, y, stat_partials, Mg, groups, K, N, geom, st);
-  if (t.bm == 128 && t.bn == 64) return td::cv_launch<128, 64>(x, w, y, stat_partials, Mg, groups, K, N, geom, st);
-  return td::cv_launch<64, 64>(x, w, y, stat_partials, Mg, groups, K, N, geom, st);
+  const td::BnRows rows = td::bn_shrink_partials_to(in_partials, in_rows, groups, K, td::CV_PRO_MAX_S, st);
+  td::CvFuse fz = {};
+  fz.part = in_partials; fz.part_S = rows.n; fz.part_stride = rows.stride; fz.part_rows = in_rows;
+  fz.gamma = gamma; fz.beta = beta; fz.mean = save_mean; fz.invstd = save_invstd; fz.rmean = running_mean; fz.rvar = running_var;
+  fz.momentum = momentum; fz.eps = eps; fz.a_side = (__hip_bfloat16*)a_side; fz.G = groups;
+  return td::cv_dispatch<false, 1, 0>(z, w, y, stat_partials, M, groups, K, N, td::ConvRows{0, 0, 0, 0, 1}, st, fz);
+}
+
+// Data gradient dX[M, Cin] = dY[M, Cout] . W[Cout, Cin] (stride 1).
+extern "C" int td_conv1x1_dgrad(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* residual,
+                                void* dx, td_stream_t stream) {
+  if (!dy || !w || !dx || !cv_shape_ok(M, groups, Cout, Cin)) return TD_ERR_BAD_ARG;
+  if (M * (long long)(Cout > Cin ? Cout : Cin) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  td::CvFuse fz = {};
+  fz.ep.res = (const __hip_bfloat16*)residual;
+  const td::ConvRows geom = {0, 0, 0, 0, 1};
+  if (residual) return td::cv_dispatch<true, 0, 1>(dy, w, dx, nullptr, M, groups, Cout, Cin, geom, (hipStream_t)stream, fz);
+  return td::cv_dispatch<true, 0, 0>(dy, w, dx, nullptr, M, groups, Cout, Cin, geom, (hipStream_t)stream, fz);
+}
+
+extern "C" int td_conv1x1_dgrad_bnsums(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* z,
+                                       const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                                       void* dx, float* out_partials, td_stream_t stream) {
+  if (!dy || !w || !dx || !z || !gamma || !beta || !save_mean || !save_invstd || !out_partials || !cv_shape_ok(M, groups, Cout, Cin))
+    return TD_ERR_BAD_ARG;
+  if (M * (long long)(Cout > Cin ? Cout : Cin) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  td::CvFuse fz = {};
+  fz.ep.z = (const __hip_bfloat16*)z; fz.ep.gamma = gamma; fz.ep.beta = beta; fz.ep.mean = save_mean; fz.ep.invstd = save_invstd;
+  return td::cv_dispatch<true, 0, 2>(dy, w, dx, out_partials, M, groups, Cout, Cin, td::ConvRows{0, 0, 0, 0, 1}, (hipStream_t)stream, fz);
+}
+
+extern "C" int td_conv1x1_dgrad_bnbwd(const void* g, const void* z, const void* w, long long M, int groups, int Cout, int Cin,
+                                      float* in_partials, int in_rows, const float* gamma, const float* beta, const float* save_mean,
+                                      const float* save_invstd, float* dgamma, float* dbeta, void* dz_side, const void* residual,
+                                      void* dx, td_stream_t stream) {
+  if (!g || !z || !w || !dx || !in_partials || in_rows < 1 || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta ||
+      !cv_shape_ok(M, groups, Cout, Cin))
+    return TD_ERR_BAD_ARG;
+  if (Cout > td::CV_PRO_MAX_K || M * (long long)(Cout > Cin ? Cout : Cin) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const td::BnRows rows = td::bn_shrink_partials_to(in_partials, in_rows, groups, Cout, td::CV_PRO_MAX_S, st);
+  td::CvFuse fz = {};
+  fz.a2 = (const __hip_bfloat16*)z; fz.part = in_partials; fz.part_S = rows.n; fz.part_stride = rows.stride; fz.part_rows = in_rows;
+  fz.gamma = gamma; fz.beta = beta; fz.mean = const_cast<float*>(save_mean); fz.invstd = const_cast<float*>(save_invstd);
+  fz.dgamma = dgamma; fz.dbeta = dbeta; fz.a_side = (__hip_bfloat16*)dz_side; fz.G = groups;
+  fz.ep.res = (const __hip_bfloat16*)residual;
+  const td::ConvRows geom = {0, 0, 0, 0, 1};
+  if (residual) return td::cv_dispatch<true, 2, 1>(g, w, dx, nullptr, M, groups, Cout, Cin, geom, st, fz);
+  return td::cv_dispatch<true, 2, 0>(g, w, dx, nullptr, M, groups, Cout, Cin, geom, st, fz);
 }
 
 extern "C" long long td_conv1x1_wgrad_workspace_floats(long long M, int K, int N) {

@@ -17,11 +17,16 @@ constexpr int CV_THREADS = 256;
 // byte offset of 16-byte chunk c (0..7) of row r in a [rows][64 bf16] stage
 __device__ __forceinline__ int cv_swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-template <int BM, int BN>
+// BT: the weight operand is stored [reduction][N] (N contiguous) -- the data gradient dX = dY . W reads the forward's [Cout][Cin]
+// weight as it lies.  Its stage tile is kept in LDS in that natural layout ([64 reduction rows][BN columns], pitch BN * 2 + 64
+// bytes: pitch mod 256 in {64, 192} makes the four rows a ds_read_b64_tr_b16 half-wave touches hit disjoint banks) and the MFMA
+// fragments come back through the hardware transpose.
+template <int BM, int BN, bool BT = false>
 struct CvTile {
   static constexpr int WM = BM / 2, WN = BN / 2;          // wave tile: WM pixels x WN channels
   static constexpr int TM = WM / 32, TN = WN / 32;
-  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int PITCH_T = BN * 2 + 64;             // BT: bytes per reduction row of the weight tile
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BT ? 64 * PITCH_T : BN * 128, STAGE = A_BYTES + B_BYTES;
   static constexpr int PITCH = BN * 2 + 8;                // epilogue image row pitch (bytes): 8-byte stores conflict-free
   static constexpr int CX = BN / 8;                       // 8-channel vectors per pixel row of the tile
   static constexpr int RSTEP = CV_THREADS / CX;           // pixel rows covered per pass of the store loop
@@ -41,17 +46,38 @@ __device__ __forceinline__ int cv_xcd_tile(int b, int total_blocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-// one 64-deep K stage: D[n][pixel] += W-tile (sb: [BN][64] swizzled) x X-tile (sa: [BM][64] swizzled)
-template <int BM, int BN>
+// MFMA operand fragment out of a [rows][cols] bf16 tile kept as it lies in memory (pitch bytes per row), for the 32 columns
+// col0.. and the reduction rows 16 ks .. 16 ks + 15: lane l -> column col0 + (l & 31), rows 16 ks + 8 (l >> 5) + 0..7, through
+// two ds_read_b64_tr_b16 (EXEC must be all ones)
+template <int PITCH>
+__device__ __forceinline__ cv_bf16x8 cv_frag_tr(const unsigned char* tile, int col0, int ks, int lane) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const int g = lane >> 4, i = lane & 15;
+  const int row = 16 * ks + 8 * (g >> 1) + (i >> 2);
+  const unsigned char* p = tile + row * PITCH + (col0 + 16 * (g & 1) + 4 * (i & 3)) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * PITCH));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(cv_bf16x8, v);
+}
+
+// one 64-deep K stage: D[n][pixel] += W-tile (sb: [BN][64] swizzled, or [64][BN] natural with BT) x X-tile (sa: [BM][64] swizzled)
+template <int BM, int BN, bool BT = false>
 __device__ __forceinline__ void cv_stage_mfma(CvAcc<BM, BN>& acc, const unsigned char* sa,
                                               const unsigned char* sb, int wm, int wn, int l31, int h) {
-  using T = CvTile<BM, BN>;
+  using T = CvTile<BM, BN, BT>;
 #pragma unroll
   for (int kk = 0; kk < CV_BK / 16; ++kk) {
     cv_bf16x8 fw[T::TN], fx[T::TM];
 #pragma unroll
-    for (int i = 0; i < T::TN; ++i)
-      fw[i] = __builtin_bit_cast(cv_bf16x8, *reinterpret_cast<const uint4*>(sb + cv_swz(wn * T::WN + i * 32 + l31, 2 * kk + h)));
+    for (int i = 0; i < T::TN; ++i) {
+      if constexpr (BT)
+        fw[i] = cv_frag_tr<T::PITCH_T>(sb, wn * T::WN + i * 32, kk, l31 + 32 * h);
+      else
+        fw[i] = __builtin_bit_cast(cv_bf16x8, *reinterpret_cast<const uint4*>(sb + cv_swz(wn * T::WN + i * 32 + l31, 2 * kk + h)));
+    }
 #pragma unroll
     for (int j = 0; j < T::TM; ++j)
       fx[j] = __builtin_bit_cast(cv_bf16x8, *reinterpret_cast<const uint4*>(sa + cv_swz(wm * T::WM + j * 32 + l31, 2 * kk + h)));
@@ -62,12 +88,28 @@ __device__ __forceinline__ void cv_stage_mfma(CvAcc<BM, BN>& acc, const unsigned
   }
 }
 
+// What the epilogue does besides storing the tile (EPI):
+//   0  nothing, or with ws: the FORWARD statistics of the BatchNorm that follows (sum y, sum y^2 of the bf16-rounded outputs)
+//   1  adds `res` (same [M, N] layout) to the rounded outputs and rounds again -- exactly the bf16 tensor add autograd would run
+//      behind the convolution's data gradient (the residual branch of a ResNet block: dx = dgrad(conv1) + d(shortcut))
+//   2  the BACKWARD sums of the BatchNorm whose output this tensor is the gradient of (data gradient of the convolution that
+//      consumed relu(bn(z))): ws <- (sum g, sum g (z - mean)) with g = y * [fma(z, gamma invstd, beta - mean gamma invstd) > 0],
+//      i.e. td_bn_bwd's statistics pass (relu mask recomputed from z) without reading the gradient back
+struct CvEpi {
+  const __hip_bfloat16* res;      // EPI 1: [M, N]
+  const __hip_bfloat16* z;        // EPI 2: [M, N] input of the BatchNorm
+  const float* gamma;             // EPI 2: [N]
+  const float* beta;              // EPI 2: [N]
+  const float* mean;              // EPI 2: [G, N] (this block's group selected by the caller)
+  const float* invstd;            // EPI 2: [G, N]
+};
+
 // accumulators -> bf16 image [pixel][channel] in LDS (the stages must be free: call behind the K loop's last barrier) -> global in
-// whole pixel rows (16 bytes per lane) [+ bias] and, with ws, the BatchNorm partial sums of this tile from the bf16-rounded values
-template <int BM, int BN>
+// whole pixel rows (16 bytes per lane) and, with ws, per-channel partial sums of this tile (EPI 0 / 2 above)
+template <int BM, int BN, int EPI = 0>
 __device__ __forceinline__ void cv_epilogue(CvAcc<BM, BN>& acc, unsigned char* lds,
                                             __hip_bfloat16* __restrict__ y, float* __restrict__ ws, long long row0, int rows_valid, int n0,
-                                            int N, long long stat_row, int tid, int wm, int wn, int l31, int h) {
+                                            int N, long long stat_row, int tid, int wm, int wn, int l31, int h, const CvEpi& ep = CvEpi{}) {
   using T = CvTile<BM, BN>;
   unsigned char* img = lds;
 #pragma unroll
@@ -88,26 +130,65 @@ __device__ __forceinline__ void cv_epilogue(CvAcc<BM, BN>& acc, unsigned char* l
   float sa8[8], sq8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sa8[e] = 0.f; sq8[e] = 0.f; }
+  float esc[8], esh[8], emu[8];
+  if constexpr (EPI == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = n0 + cx * 8 + e;
+      emu[e] = ep.mean[c];
+      esc[e] = ep.gamma[c] * ep.invstd[c];
+      esh[e] = ep.beta[c] - emu[e] * esc[e];
+    }
+  }
+  const bool stats = ws != nullptr;
 #pragma unroll 4
   for (int r = ry; r < BM; r += T::RSTEP) {
     const uint2 lo = *reinterpret_cast<const uint2*>(img + r * T::PITCH + cx * 16);
     const uint2 hi = *reinterpret_cast<const uint2*>(img + r * T::PITCH + cx * 16 + 8);
     if (r < rows_valid) {
-      *reinterpret_cast<uint4*>(y + (row0 + r) * (long long)N + n0 + cx * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      if (ws) {
-        const unsigned wv[4] = {lo.x, lo.y, hi.x, hi.y};
+      unsigned wv[4] = {lo.x, lo.y, hi.x, hi.y};
+      const long long off = (row0 + r) * (long long)N + n0 + cx * 8;
+      if constexpr (EPI == 1) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(ep.res + off);
+        const unsigned rv[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v0 = bf2f((unsigned short)(wv[e] & 0xffff)), v1 = bf2f((unsigned short)(wv[e] >> 16));
-          sa8[2 * e] += v0;
-          sq8[2 * e] = fmaf(v0, v0, sq8[2 * e]);
-          sa8[2 * e + 1] += v1;
-          sq8[2 * e + 1] = fmaf(v1, v1, sq8[2 * e + 1]);
+          const float v0 = bf2f((unsigned short)(wv[e] & 0xffff)) + bf2f((unsigned short)(rv[e] & 0xffff));
+          const float v1 = bf2f((unsigned short)(wv[e] >> 16)) + bf2f((unsigned short)(rv[e] >> 16));
+          wv[e] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(y + off) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      if constexpr (EPI == 0) {
+        if (stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v0 = bf2f((unsigned short)(wv[e] & 0xffff)), v1 = bf2f((unsigned short)(wv[e] >> 16));
+            sa8[2 * e] += v0;
+            sq8[2 * e] = fmaf(v0, v0, sq8[2 * e]);
+            sa8[2 * e + 1] += v1;
+            sq8[2 * e + 1] = fmaf(v1, v1, sq8[2 * e + 1]);
+          }
+        }
+      }
+      if constexpr (EPI == 2) {
+        const uint4 zz = *reinterpret_cast<const uint4*>(ep.z + off);
+        const unsigned zv[4] = {zz.x, zz.y, zz.z, zz.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z0 = bf2f((unsigned short)(zv[e] & 0xffff)), z1 = bf2f((unsigned short)(zv[e] >> 16));
+          float g0 = bf2f((unsigned short)(wv[e] & 0xffff)), g1 = bf2f((unsigned short)(wv[e] >> 16));
+          g0 = fmaf(z0, esc[2 * e], esh[2 * e]) <= 0.f ? 0.f : g0;
+          g1 = fmaf(z1, esc[2 * e + 1], esh[2 * e + 1]) <= 0.f ? 0.f : g1;
+          sa8[2 * e] += g0;
+          sq8[2 * e] = fmaf(g0, z0 - emu[2 * e], sq8[2 * e]);
+          sa8[2 * e + 1] += g1;
+          sq8[2 * e + 1] = fmaf(g1, z1 - emu[2 * e + 1], sq8[2 * e + 1]);
         }
       }
     }
   }
-  if (ws) {
+  if (stats) {
     float* red = reinterpret_cast<float*>(lds + T::IMG_BYTES);        // [2][RSTEP][BN + 1], behind the image
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

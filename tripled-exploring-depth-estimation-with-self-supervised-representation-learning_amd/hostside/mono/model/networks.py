@@ -216,6 +216,7 @@ def bn_act(bn, x, residual=None, relu=True):
 
 
 FUSED_1X1_OFF = bool(os.environ.get("TD_NO_MFMA_1X1"))
+FUSED_BLOCK_OFF = bool(os.environ.get("TD_NO_FUSED_BLOCK"))      # bottlenecks as per-layer autograd nodes (round 3's path)
 
 
 def conv_bn_act(conv, bn, x, residual=None, relu=True):
@@ -345,7 +346,41 @@ class Bottleneck(nn.Module):
             return conv_bn_act(ds[0], ds[1], x, relu=False)
         return ds(x)
 
+    def _fused(self, x):
+        """The block as one autograd node over the fused kernels (tripled_amd.ops.bottleneck: BatchNorm passes folded into the
+        1x1 GEMMs' operand staging / epilogues, both data gradients hand-written), or None when the layout is not one it takes."""
+        if FUSED_BLOCK_OFF or FUSED_1X1_OFF or _FP8_1X1[0] or not (self.training and x.is_cuda and torch.is_grad_enabled()):
+            return None
+        if not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+            return None
+        ds = self.downsample
+        bns = [self.bn1, self.bn2, self.bn3]
+        wd = bnd = None
+        if ds is not None:
+            if not (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and ds[0].kernel_size == (1, 1)
+                    and ds[0].bias is None and ds[0].stride == (self.stride, self.stride)):
+                return None
+            wd, bnd = ds[0].weight, ds[1]
+            bns.append(bnd)
+        if not all(isinstance(b, BatchNorm) and b._sync is None and b._hip_ok_params() for b in bns):
+            return None
+        if any(cv.bias is not None or cv.groups != 1 for cv in (self.conv1, self.conv2, self.conv3)):
+            return None
+        bf = lambda w: w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        xb = _dense_cl(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
+        w1, w2, w3 = bf(self.conv1.weight), bf(self.conv2.weight), bf(self.conv3.weight)
+        wd = bf(wd) if wd is not None else None
+        if not _ops().bottleneck_supported(xb, w1, w2, w3, self.bn1.weight, wd, self.stride):
+            return None
+        g = _BN_GROUPS[0]
+        for b in bns:
+            b._pending += g
+        return _ops().bottleneck(xb, w1, self.bn1, w2, self.bn2, w3, self.bn3, wd, bnd, groups=g, stride=self.stride)
+
     def forward(self, x):
+        y = self._fused(x)
+        if y is not None:
+            return y
         y = conv_bn_act(self.conv1, self.bn1, x)
         y = bn_act(self.bn2, self.conv2(y))
         return conv_bn_act(self.conv3, self.bn3, y, self._shortcut(x))

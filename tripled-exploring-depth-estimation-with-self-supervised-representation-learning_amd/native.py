@@ -22,7 +22,7 @@ _PTRARR = ctypes.POINTER(ctypes.c_void_p)
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _LLARR = ctypes.POINTER(ctypes.c_longlong)     # host arrays
 _IARR = ctypes.POINTER(ctypes.c_int)
-ABI_VERSION = 2      # include/tripled_hip.h: TD_ABI_VERSION
+ABI_VERSION = 3      # include/tripled_hip.h: TD_ABI_VERSION
 
 SIGNATURES = {
     "td_abi_version": (_I, []),
@@ -59,6 +59,14 @@ SIGNATURES = {
     "td_conv1x1_wgrad_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _I]),
     "td_conv1x1_wgrad": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_bn_fwd_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "td_bn_partial_rows": (_I, [ctypes.c_longlong, _I, _I]),
+    "td_bn_fwd_partials": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _P, _P]),
+    "td_bn_bwd_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P]),
+    "td_bn_bwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "td_conv1x1_fwd_bnrelu": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "td_conv1x1_dgrad": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P]),
+    "td_conv1x1_dgrad_bnsums": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "td_conv1x1_dgrad_bnbwd": (_I, [_P, _P, _P, ctypes.c_longlong, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "td_bn_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P, _P, _P]),
     "td_edge_weights": (_I, [_P, _I, _I, _I, _F, ctypes.POINTER(ctypes.c_float), _P, _P]),
     "td_featreg_num_blocks": (_I, [_I, _I, _I, _I]),

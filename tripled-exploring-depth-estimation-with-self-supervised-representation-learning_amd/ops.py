@@ -505,6 +505,214 @@ def conv1x1_bn_act(x, w, weight, bias, running_mean, running_var, momentum, eps,
     return _Conv1x1BatchNormAct.apply(x, w, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, stride)
 
 
+class BnState:
+    """What a BatchNorm layer contributes to a fused block: affine parameters are passed as tensors (autograd), the rest here."""
+    __slots__ = ("running_mean", "running_var", "momentum", "eps")
+
+    def __init__(self, bn):
+        self.running_mean, self.running_var = bn.running_mean, bn.running_var
+        self.momentum, self.eps = float(bn.momentum), float(bn.eps)
+
+
+def _cl_empty(n, c, h, w, like):
+    return torch.empty((n, c, h, w), device=like.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+
+
+class _Bottleneck(torch.autograd.Function):
+    """The whole ResNet bottleneck (reference: Bottleneck.forward, mono/model/mono_fm_joint/resnet.py:66-86) as ONE autograd
+    node, so that BatchNorm work can ride on the neighbouring 1x1 GEMMs across layer boundaries (csrc/td_conv1x1.hip, "fused
+    forms"):
+
+      forward   conv1 GEMM (+ bn1 statistics) -> bn1 apply + relu -> conv2 (3x3: MIOpen) -> bn2 statistics pass
+                -> conv3 GEMM with relu(bn2(.)) applied to its operand while it is staged (+ bn3 statistics)
+                -> [down-sample GEMM + bn] -> bn3 apply + identity + relu
+      backward  bn3 backward -> conv3 data gradient whose epilogue forms bn2's backward sums; conv3 weight gradient
+                -> bn2 dx -> conv2 backward (MIOpen) -> bn1 statistics pass
+                -> conv1 data gradient with bn1's backward applied to its operand while it is staged and the identity
+                   branch's gradient added in its epilogue; conv1 weight gradient
+
+    Against the per-layer nodes this drops the bn2 apply pass, the bn2 backward statistics pass, the bn1 dx pass and the
+    residual-gradient add (4 launches and their passes over the activations per block), and both data gradients run on the
+    hand-written MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, g1, b1, g2, b2, g3, b3, wd, gd, bd, st1, st2, st3, std, groups, stride):
+        lib = native.load()
+        strm = native.stream()
+        Nb, Cin, H, W = x.shape
+        c = w1.shape[0]
+        Cout = w3.shape[0]
+        M1 = Nb * H * W
+        f32 = dict(device=x.device, dtype=torch.float32)
+
+        def gemm_stats(inp, w, M, K, N, Hi, Wi, s_):
+            y = _cl_empty(Nb, N, (Hi - 1) // s_ + 1, (Wi - 1) // s_ + 1, x)
+            S = lib.td_conv1x1_stat_rows(M, groups, N)
+            part = torch.empty(groups * S * N * 2, **f32)
+            native.check(lib.td_conv1x1_fwd(_raw(inp), _raw(w), M, groups, K, N, Hi, Wi, s_, _raw(y), native.ptr(part), strm),
+                         "td_conv1x1_fwd")
+            return y, part, S
+
+        def apply(z, part, S, gamma, beta, st, M, C, res, relu):
+            y = torch.empty_like(z, memory_format=torch.channels_last)
+            mean, invstd = torch.empty(groups * C, **f32), torch.empty(groups * C, **f32)
+            native.check(lib.td_bn_fwd_from_partials(_raw(z), _raw(res) if res is not None else None, native.DTYPE_CODES[z.dtype],
+                                                     native.ptr(gamma), native.ptr(beta), native.ptr(st.running_mean),
+                                                     native.ptr(st.running_var), st.momentum, st.eps, int(relu), M, groups, C,
+                                                     native.ptr(part), S, _raw(y), native.ptr(mean), native.ptr(invstd), strm),
+                         "td_bn_fwd_from_partials")
+            return y, mean, invstd
+
+        # conv1 -> bn1 -> relu
+        z1, p1, S1 = gemm_stats(x, w1, M1, Cin, c, H, W, 1)
+        a1, mean1, invstd1 = apply(z1, p1, S1, g1, b1, st1, M1, c, None, True)
+        # conv2 (3x3, stride s): MIOpen
+        z2 = torch.ops.aten.convolution(a1, w2, None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1)
+        if not z2.is_contiguous(memory_format=torch.channels_last):
+            z2 = z2.contiguous(memory_format=torch.channels_last)
+        Ho, Wo = z2.shape[2], z2.shape[3]
+        M2 = Nb * Ho * Wo
+        # bn2 statistics pass; its apply + relu ride on conv3's operand staging
+        R2 = lib.td_bn_partial_rows(M2, groups, c)
+        p2 = torch.empty(groups * R2 * c * 2, **f32)
+        native.check(lib.td_bn_fwd_partials(_raw(z2), native.DTYPE_CODES[z2.dtype], M2, groups, c, native.ptr(p2), strm),
+                     "td_bn_fwd_partials")
+        z3 = _cl_empty(Nb, Cout, Ho, Wo, x)
+        a2 = _cl_empty(Nb, c, Ho, Wo, x)
+        S3 = lib.td_conv1x1_stat_rows(M2, groups, Cout)
+        p3 = torch.empty(groups * S3 * Cout * 2, **f32)
+        mean2, invstd2 = torch.empty(groups * c, **f32), torch.empty(groups * c, **f32)
+        native.check(lib.td_conv1x1_fwd_bnrelu(_raw(z2), _raw(w3), M2, groups, c, Cout, native.ptr(p2), R2, native.ptr(g2),
+                                               native.ptr(b2), native.ptr(st2.running_mean), native.ptr(st2.running_var),
+                                               st2.momentum, st2.eps, native.ptr(mean2), native.ptr(invstd2), _raw(a2), _raw(z3),
+                                               native.ptr(p3), strm), "td_conv1x1_fwd_bnrelu")
+        # identity branch
+        zd = meand = invstdd = None
+        if wd is not None:
+            zd, pd, Sd = gemm_stats(x, wd, M2, Cin, Cout, H, W, stride)
+            shortcut, meand, invstdd = apply(zd, pd, Sd, gd, bd, std, M2, Cout, None, False)
+        else:
+            shortcut = x
+        y, mean3, invstd3 = apply(z3, p3, S3, g3, b3, st3, M2, Cout, shortcut, True)
+        ctx.save_for_backward(x, w1, w2, w3, g1, b1, g2, b2, g3, b3, wd, gd, bd, z1, a1, z2, a2, z3, y, zd, mean1, invstd1,
+                              mean2, invstd2, mean3, invstd3, meand, invstdd)
+        ctx.groups, ctx.stride = groups, stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = native.load()
+        strm = native.stream()
+        (x, w1, w2, w3, g1, b1, g2, b2, g3, b3, wd, gd, bd, z1, a1, z2, a2, z3, y, zd, mean1, invstd1, mean2, invstd2, mean3,
+         invstd3, meand, invstdd) = ctx.saved_tensors
+        groups, stride = ctx.groups, ctx.stride
+        Nb, Cin, H, W = x.shape
+        c, Cout = w1.shape[0], w3.shape[0]
+        Ho, Wo = z2.shape[2], z2.shape[3]
+        M1, M2 = Nb * H * W, Nb * Ho * Wo
+        f32 = dict(device=x.device, dtype=torch.float32)
+        BF = native.DTYPE_CODES[torch.bfloat16]
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+        def wgrad(dz, inp, w, M, K, N, Hi, Wi, s_):
+            dw = torch.empty_like(w)
+            wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), **f32)
+            native.check(lib.td_conv1x1_wgrad(_raw(dz), _raw(inp), M, K, N, Hi, Wi, s_, native.DTYPE_CODES[w.dtype], _raw(dw),
+                                              native.ptr(wsw), strm), "td_conv1x1_wgrad")
+            return dw
+
+        def bn_bwd(dyy, zz, yy, gamma, beta, mean, invstd, relu, M, C, want_res):
+            dz = torch.empty_like(zz, memory_format=torch.channels_last)
+            dres = torch.empty_like(zz, memory_format=torch.channels_last) if want_res else None
+            dg, db = torch.empty(C, **f32), torch.empty(C, **f32)
+            ws = torch.empty(lib.td_bn_workspace_floats(M, groups, C), **f32)
+            native.check(lib.td_bn_bwd(_raw(dyy), _raw(zz), _raw(yy) if yy is not None else None, BF, native.ptr(gamma),
+                                       native.ptr(beta), native.ptr(mean), native.ptr(invstd), int(relu), M, groups, C, _raw(dz),
+                                       _raw(dres) if dres is not None else None, native.ptr(dg), native.ptr(db), native.ptr(ws),
+                                       strm), "td_bn_bwd")
+            return dz, dres, dg, db
+
+        # bn3 (+ relu, + identity): dz3 and the identity branch's gradient (dy masked by the block's relu)
+        dz3, dres, dg3, db3 = bn_bwd(dy, z3, y, g3, b3, mean3, invstd3, True, M2, Cout, True)
+        # conv3: data gradient with bn2's backward sums in the epilogue; weight gradient against relu(bn2(z2))
+        da2 = torch.empty_like(z2, memory_format=torch.channels_last)
+        S2 = lib.td_conv1x1_stat_rows(M2, groups, c)
+        q2 = torch.empty(groups * S2 * c * 2, **f32)
+        native.check(lib.td_conv1x1_dgrad_bnsums(_raw(dz3), _raw(w3), M2, groups, Cout, c, _raw(z2), native.ptr(g2), native.ptr(b2),
+                                                 native.ptr(mean2), native.ptr(invstd2), _raw(da2), native.ptr(q2), strm),
+                     "td_conv1x1_dgrad_bnsums")
+        dw3 = wgrad(dz3, a2, w3, M2, c, Cout, Ho, Wo, 1)
+        # bn2 dx from those sums
+        dz2 = torch.empty_like(z2, memory_format=torch.channels_last)
+        dg2, db2 = torch.empty(c, **f32), torch.empty(c, **f32)
+        native.check(lib.td_bn_bwd_from_partials(_raw(da2), _raw(z2), None, BF, native.ptr(g2), native.ptr(b2), native.ptr(mean2),
+                                                 native.ptr(invstd2), 1, M2, groups, c, native.ptr(q2), S2, _raw(dz2), None,
+                                                 native.ptr(dg2), native.ptr(db2), strm), "td_bn_bwd_from_partials")
+        # conv2: MIOpen
+        da1, dw2, _ = torch.ops.aten.convolution_backward(dz2, a1, w2, None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1,
+                                                          [True, True, False])
+        if not da1.is_contiguous(memory_format=torch.channels_last):
+            da1 = da1.contiguous(memory_format=torch.channels_last)
+        # bn1 statistics pass; its dx rides on conv1's data gradient
+        R1 = lib.td_bn_partial_rows(M1, groups, c)
+        q1 = torch.empty(groups * R1 * c * 2, **f32)
+        native.check(lib.td_bn_bwd_partials(_raw(da1), _raw(z1), None, BF, native.ptr(g1), native.ptr(b1), native.ptr(mean1),
+                                            native.ptr(invstd1), 1, M1, groups, c, native.ptr(q1), strm), "td_bn_bwd_partials")
+        # identity branch: x itself, or the down-sample convolution + bn
+        dwd = dgd = dbd = None
+        if wd is not None:
+            dzd, _, dgd, dbd = bn_bwd(dres, zd, None, gd, bd, meand, invstdd, False, M2, Cout, False)
+            if stride == 1:
+                res_in = torch.empty_like(x, memory_format=torch.channels_last)
+                native.check(lib.td_conv1x1_dgrad(_raw(dzd), _raw(wd), M2, groups, Cout, Cin, None, _raw(res_in), strm),
+                             "td_conv1x1_dgrad")
+            else:      # strided 1x1: the gradient lands on every stride-th pixel (MIOpen writes the zeros in between)
+                res_in = torch.ops.aten.convolution_backward(dzd, x, wd, None, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1,
+                                                             [True, False, False])[0]
+                if res_in.dtype != torch.bfloat16 or not res_in.is_contiguous(memory_format=torch.channels_last):
+                    res_in = res_in.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dwd = wgrad(dzd, x, wd, M2, Cin, Cout, H, W, stride)
+        else:
+            res_in = dres
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dz1 = torch.empty_like(z1, memory_format=torch.channels_last)
+        dg1, db1 = torch.empty(c, **f32), torch.empty(c, **f32)
+        native.check(lib.td_conv1x1_dgrad_bnbwd(_raw(da1), _raw(z1), _raw(w1), M1, groups, c, Cin, native.ptr(q1), R1, native.ptr(g1),
+                                                native.ptr(b1), native.ptr(mean1), native.ptr(invstd1), native.ptr(dg1),
+                                                native.ptr(db1), _raw(dz1), _raw(res_in), _raw(dx), strm), "td_conv1x1_dgrad_bnbwd")
+        dw1 = wgrad(dz1, x, w1, M1, Cin, c, H, W, 1)
+        cast = lambda t, like: None if t is None else t.to(like.dtype)
+        return (dx, dw1, dw2, dw3, cast(dg1, g1), cast(db1, b1), cast(dg2, g2), cast(db2, b2), cast(dg3, g3), cast(db3, b3),
+                dwd, cast(dgd, gd) if gd is not None else None, cast(dbd, bd) if bd is not None else None,
+                None, None, None, None, None, None)
+
+
+def bottleneck_supported(x, w1, w2, w3, g1, wd=None, stride=1):
+    bf, cl = torch.bfloat16, torch.channels_last
+    ok_w = lambda w: w.dtype == bf and (w.is_contiguous() or w.is_contiguous(memory_format=cl))
+    c = w1.shape[0]
+    return (x.is_cuda and x.dim() == 4 and x.dtype == bf and x.is_contiguous(memory_format=cl) and ok_w(w1) and ok_w(w3)
+            and w2.dtype == bf and w2.is_contiguous(memory_format=cl) and g1.dtype == torch.float32
+            and x.shape[1] % 64 == 0 and c % 64 == 0 and c <= 512 and w3.shape[0] % 64 == 0 and stride in (1, 2)
+            and tuple(w1.shape[1:]) == (x.shape[1], 1, 1) and tuple(w3.shape[1:]) == (c, 1, 1) and tuple(w2.shape) == (c, c, 3, 3)
+            and (wd is None or (ok_w(wd) and tuple(wd.shape) == (w3.shape[0], x.shape[1], 1, 1)))
+            and (wd is not None or (stride == 1 and w3.shape[0] == x.shape[1])))
+
+
+def bottleneck(x, w1, bn1, w2, bn2, w3, bn3, wd=None, bnd=None, groups=1, stride=1):
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)) in training mode (reference: resnet.py:66-86), one
+    autograd node over the fused kernels; bn* are the BatchNorm modules (affine parameters differentiable, running statistics
+    updated in place)."""
+    if x.shape[0] % groups:
+        raise ValueError("batch %d is not %d stacked passes" % (x.shape[0], groups))
+    if not bottleneck_supported(x, w1, w2, w3, bn1.weight, wd, stride):
+        raise native.NativeLibraryError("bottleneck needs bf16 channels_last HIP tensors, channels % 64 == 0, planes <= 512")
+    return _Bottleneck.apply(x, w1, w2, w3, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn3.weight, bn3.bias, wd,
+                             bnd.weight if bnd is not None else None, bnd.bias if bnd is not None else None,
+                             BnState(bn1), BnState(bn2), BnState(bn3), BnState(bnd) if bnd is not None else None, groups, stride)
+
+
 def batchnorm_act_supported(x, weight):
     return (x.is_cuda and x.dim() == 4 and x.dtype in native.DTYPE_CODES and x.shape[1] % 64 == 0
             and weight is not None and weight.dtype == torch.float32

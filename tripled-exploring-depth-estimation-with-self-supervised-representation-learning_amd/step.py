@@ -28,6 +28,16 @@ class NonFiniteLossError(RuntimeError):
     """The training loss (or a parameter) stopped being finite."""
 
 
+def reduce_loss(name, value):
+    """One entry of the model's loss dict as a scalar, like the reference's batch_processor (mono/apis/trainer.py:40-49):
+    a tensor contributes its mean, a list of tensors the sum of their means, anything else is a TypeError."""
+    if torch.is_tensor(value):
+        return value.float().mean()
+    if isinstance(value, list):
+        return sum(v.float().mean() for v in value)
+    raise TypeError("%s is not a tensor or list of tensors" % (name,))
+
+
 class TrainStep:
     """zero-grad -> forward -> sum of loss means -> backward -> [grad sync] -> clip -> Adam.
 
@@ -86,7 +96,7 @@ class TrainStep:
             data = self.prepare(data)
         with torch.autocast(self.device.type, dtype=self.dtype, enabled=self.dtype is not None):
             outputs, losses = self.model(data)
-        means = OrderedDict((k, v.float().mean()) for k, v in losses.items())
+        means = OrderedDict((k, reduce_loss(k, v)) for k, v in losses.items())
         total = sum(means.values())
         total.backward()
         if self.flat is not None:
@@ -345,7 +355,8 @@ class RunnerIteration:
         self.step.loss, self.step.losses = self._graph_out
         self.replays += 1
         if self.replays <= 2:       # the health gate of capture_step, on the first real replays (host sync, twice)
-            torch.cuda.synchronize()
+            if self.step.device.type == "cuda":
+                torch.cuda.synchronize()
             self.step.check_finite("replay %d of the captured training iteration" % self.replays)
         return self._result(n)
 
