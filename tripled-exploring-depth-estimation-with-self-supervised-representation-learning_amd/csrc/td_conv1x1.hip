@@ -112,7 +112,7 @@ __device__ __forceinline__ void cv_sum_rows(const float* __restrict__ part, int 
   }
 }
 
-template <int BM, int BN, bool BT, int PRO, int EPI>
+template <int BM, int BN, bool BT, int PRO, int EPI, bool DEEP>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     const __hip_bfloat16* __restrict__ x, const __hip_bfloat16* __restrict__ w, __hip_bfloat16* __restrict__ y,
     float* __restrict__ ws, long long Mg, int K, int N, int tiles_per_group, int total_blocks, ConvRows geom, CvFuse fz) {
@@ -151,24 +151,31 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
   const long long bstep = BT ? (long long)RPP * N : 32ll * K;
   const __hip_bfloat16 *pb1 = pb0 + bstep, *pb2 = pb0 + (NB > 2 ? 2 : 0) * bstep, *pb3 = pb0 + (NB > 2 ? 3 : 0) * bstep;
   const long long bkt = BT ? (long long)CV_BK * N : (long long)CV_BK;     // weight pointer advance per K stage
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rz0, rz1, rz2, rz3;
-  ra2 = ra3 = rb2 = rb3 = make_uint4(0, 0, 0, 0);
-  rz0 = rz1 = rz2 = rz3 = make_uint4(0, 0, 0, 0);
+  // DEEP: two register sets (A: even stages, B: odd stages), the loads run TWO stages ahead of the arithmetic.  A K stage is a few
+  // MFMAs (~0.15 us) against a global-load round trip of 1-2 us, and the deep layers have at most one block per CU, so with the
+  // loads one stage ahead every stage cost a full memory latency (K = 2048: 25 us for a 6 MB problem).  Instantiated where the
+  // second set fits without spilling (64 x 64 tiles; 128 x 64 without a prologue) and K has at least three stages.
+#define CV_DECL(S)                                                                          \
+  uint4 ra0##S, ra1##S, ra2##S, ra3##S, rb0##S, rb1##S, rb2##S, rb3##S, rz0##S, rz1##S, rz2##S, rz3##S; \
+  ra0##S = ra1##S = ra2##S = ra3##S = rb0##S = rb1##S = rb2##S = rb3##S = make_uint4(0, 0, 0, 0);       \
+  rz0##S = rz1##S = rz2##S = rz3##S = make_uint4(0, 0, 0, 0);
+  CV_DECL(A)
+  CV_DECL(B)
 #define CV_LD(p, kt) (*reinterpret_cast<const uint4*>((p) + (kt) * CV_BK))
 #define CV_LDB(p, kt) (*reinterpret_cast<const uint4*>((p) + (kt) * bkt))
-#define CV_LOAD_GLOBAL(kt)                                     \
+#define CV_LOAD_GLOBAL(kt, S)                                  \
   {                                                            \
-    ra0 = CV_LD(pa0, kt);                                      \
-    ra1 = CV_LD(pa1, kt);                                      \
-    if (NA > 2) { ra2 = CV_LD(pa2, kt); ra3 = CV_LD(pa3, kt); } \
+    ra0##S = CV_LD(pa0, kt);                                   \
+    ra1##S = CV_LD(pa1, kt);                                   \
+    if (NA > 2) { ra2##S = CV_LD(pa2, kt); ra3##S = CV_LD(pa3, kt); } \
     if constexpr (PRO == 2) {                                  \
-      rz0 = CV_LD(fz.a2 + oa0, kt);                            \
-      rz1 = CV_LD(fz.a2 + oa1, kt);                            \
-      if (NA > 2) { rz2 = CV_LD(fz.a2 + oa2, kt); rz3 = CV_LD(fz.a2 + oa3, kt); } \
+      rz0##S = CV_LD(fz.a2 + oa0, kt);                         \
+      rz1##S = CV_LD(fz.a2 + oa1, kt);                         \
+      if (NA > 2) { rz2##S = CV_LD(fz.a2 + oa2, kt); rz3##S = CV_LD(fz.a2 + oa3, kt); } \
     }                                                          \
-    rb0 = CV_LDB(pb0, kt);                                     \
-    rb1 = CV_LDB(pb1, kt);                                     \
-    if (NB > 2) { rb2 = CV_LDB(pb2, kt); rb3 = CV_LDB(pb3, kt); } \
+    rb0##S = CV_LDB(pb0, kt);                                  \
+    rb1##S = CV_LDB(pb1, kt);                                  \
+    if (NB > 2) { rb2##S = CV_LDB(pb2, kt); rb3##S = CV_LDB(pb3, kt); } \
   }
 #define CV_ST(base, i, v) (*reinterpret_cast<uint4*>((base) + cv_swz(lr + 32 * (i), lc)) = (v))
 #define CV_STB(base, i, v)                                                                              \
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     else CV_ST(base, i, v);                                                                             \
   }
   // the A operand passes through the prologue transform on its way into LDS (and, n-tile 0, out to a_side)
-#define CV_PRO_A(kt)                                                                                    \
+#define CV_PRO_A(kt, S)                                                                                 \
   {                                                                                                     \
     if constexpr (PRO != 0) {                                                                           \
       const int c0_ = (kt) * CV_BK + lc * 8;                                                            \
@@ -192,35 +199,35 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
         }                                                                                               \
       }                                                                                                 \
       if constexpr (PRO == 1) {                                                                         \
-        ra0 = cv_pro1(ra0, q0, q1);                                                                     \
-        ra1 = cv_pro1(ra1, q0, q1);                                                                     \
-        if (NA > 2) { ra2 = cv_pro1(ra2, q0, q1); ra3 = cv_pro1(ra3, q0, q1); }                         \
+        ra0##S = cv_pro1(ra0##S, q0, q1);                                                               \
+        ra1##S = cv_pro1(ra1##S, q0, q1);                                                               \
+        if (NA > 2) { ra2##S = cv_pro1(ra2##S, q0, q1); ra3##S = cv_pro1(ra3##S, q0, q1); }             \
       } else {                                                                                          \
-        ra0 = cv_pro2(ra0, rz0, q0, q1, q2, q3, q4);                                                    \
-        ra1 = cv_pro2(ra1, rz1, q0, q1, q2, q3, q4);                                                    \
-        if (NA > 2) { ra2 = cv_pro2(ra2, rz2, q0, q1, q2, q3, q4); ra3 = cv_pro2(ra3, rz3, q0, q1, q2, q3, q4); } \
+        ra0##S = cv_pro2(ra0##S, rz0##S, q0, q1, q2, q3, q4);                                           \
+        ra1##S = cv_pro2(ra1##S, rz1##S, q0, q1, q2, q3, q4);                                           \
+        if (NA > 2) { ra2##S = cv_pro2(ra2##S, rz2##S, q0, q1, q2, q3, q4); ra3##S = cv_pro2(ra3##S, rz3##S, q0, q1, q2, q3, q4); } \
       }                                                                                                 \
       if (fz.a_side && nt == 0) {                                                                       \
         __hip_bfloat16* sd_ = fz.a_side + (row0 + lr) * (long long)K + c0_;                             \
-        if (lr < rows_valid) *reinterpret_cast<uint4*>(sd_) = ra0;                                      \
-        if (lr + 32 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 32ll * K) = ra1;                      \
+        if (lr < rows_valid) *reinterpret_cast<uint4*>(sd_) = ra0##S;                                   \
+        if (lr + 32 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 32ll * K) = ra1##S;                   \
         if (NA > 2) {                                                                                   \
-          if (lr + 64 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 64ll * K) = ra2;                    \
-          if (lr + 96 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 96ll * K) = ra3;                    \
+          if (lr + 64 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 64ll * K) = ra2##S;                 \
+          if (lr + 96 < rows_valid) *reinterpret_cast<uint4*>(sd_ + 96ll * K) = ra3##S;                 \
         }                                                                                               \
       }                                                                                                 \
     }                                                                                                   \
   }
-#define CV_WRITE_LDS(stage, kt)                                          \
+#define CV_WRITE_LDS(stage, kt, S)                                       \
   {                                                                      \
     unsigned char* base_ = lds + (stage) * STAGE;                        \
-    CV_PRO_A(kt)                                                         \
-    CV_ST(base_, 0, ra0);                                                \
-    CV_ST(base_, 1, ra1);                                                \
-    if (NA > 2) { CV_ST(base_, 2, ra2); CV_ST(base_, 3, ra3); }          \
-    CV_STB(base_ + A_BYTES, 0, rb0);                                     \
-    CV_STB(base_ + A_BYTES, 1, rb1);                                     \
-    if (NB > 2) { CV_STB(base_ + A_BYTES, 2, rb2); CV_STB(base_ + A_BYTES, 3, rb3); } \
+    CV_PRO_A(kt, S)                                                      \
+    CV_ST(base_, 0, ra0##S);                                             \
+    CV_ST(base_, 1, ra1##S);                                             \
+    if (NA > 2) { CV_ST(base_, 2, ra2##S); CV_ST(base_, 3, ra3##S); }    \
+    CV_STB(base_ + A_BYTES, 0, rb0##S);                                  \
+    CV_STB(base_ + A_BYTES, 1, rb1##S);                                  \
+    if (NB > 2) { CV_STB(base_ + A_BYTES, 2, rb2##S); CV_STB(base_ + A_BYTES, 3, rb3##S); } \
   }
 
   CvAcc<BM, BN> acc;
@@ -232,7 +239,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
       for (int e = 0; e < 16; ++e) acc.v[i][j][e] = 0.f;
 
   const int nk = K / CV_BK;
-  CV_LOAD_GLOBAL(0)                       // the first tiles are on their way while the prologue finishes the statistics
+  CV_LOAD_GLOBAL(0, A)                    // the first tiles are on their way while the prologue finishes the statistics
+  if constexpr (DEEP) CV_LOAD_GLOBAL(nk > 1 ? 1 : 0, B)
 
   if constexpr (PRO == 1) {
     const float* part = fz.part + (size_t)grp * fz.part_rows * K * 2;
@@ -300,16 +308,36 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
     __syncthreads();
   }
 
-  CV_WRITE_LDS(0, 0)
+  CV_WRITE_LDS(0, 0, A)
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) CV_LOAD_GLOBAL(kt + 1)
-    const unsigned char* sa = lds + (kt & 1) * STAGE;
-    const unsigned char* sb = sa + A_BYTES;
-    cv_stage_mfma<BM, BN, BT>(acc, sa, sb, wm, wn, l31, h);
-    if (more) CV_WRITE_LDS((kt + 1) & 1, kt + 1)
-    __syncthreads();
+  if constexpr (!DEEP) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) CV_LOAD_GLOBAL(kt + 1, A)
+      const unsigned char* sa = lds + (kt & 1) * STAGE;
+      cv_stage_mfma<BM, BN, BT>(acc, sa, sa + A_BYTES, wm, wn, l31, h);
+      if (more) CV_WRITE_LDS((kt + 1) & 1, kt + 1, A)
+      __syncthreads();
+    }
+  } else {
+    // branch-free inside the stage pair: a conditional load makes the compiler's waitcnt pass drain the whole queue at the join
+    // (vmcnt(0) in front of the LDS writes, i.e. no prefetch at all); instead the stage index is clamped -- past the end the last
+    // stage is re-read and re-written into the idle buffer, which nobody reads
+    const int last = nk - 1;
+    for (int kt = 0; kt < nk; kt += 2) {
+      const int k2 = kt + 2 < last ? kt + 2 : last, k1 = kt + 1 < last ? kt + 1 : last, k3 = kt + 3 < last ? kt + 3 : last;
+      CV_LOAD_GLOBAL(k2, A)
+      __builtin_amdgcn_sched_barrier(0);       // keep the requests in front of the stage's arithmetic (the scheduler sinks them)
+      cv_stage_mfma<BM, BN, BT>(acc, lds, lds + A_BYTES, wm, wn, l31, h);
+      CV_WRITE_LDS(1, k1, B)
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      CV_LOAD_GLOBAL(k3, B)
+      __builtin_amdgcn_sched_barrier(0);
+      cv_stage_mfma<BM, BN, BT>(acc, lds + STAGE, lds + STAGE + A_BYTES, wm, wn, l31, h);
+      CV_WRITE_LDS(0, k2, A)
+      __syncthreads();
+    }
   }
 
   CvEpi ep = fz.ep;
@@ -318,6 +346,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_mfma_kernel(
 }
 
 #undef CV_LOAD_GLOBAL
+#undef CV_DECL
 #undef CV_WRITE_LDS
 #undef CV_PRO_A
 #undef CV_LD
@@ -472,13 +501,13 @@ static inline int wg_splits(long long M, int K, int N) {
   return (int)(p < 1 ? 1 : p);
 }
 
-template <int BM, int BN, bool BT = false, int PRO = 0, int EPI = 0>
+template <int BM, int BN, bool BT, int PRO, int EPI, bool DEEP>
 static int cv_launch(const void* x, const void* w, void* y, float* ws, long long Mg, int G, int K, int N, ConvRows geom, hipStream_t st,
-                     const CvFuse& fz = CvFuse{}) {
+                     const CvFuse& fz) {
   const int tpg = (int)((Mg + BM - 1) / BM);
   const long long nblk = (long long)G * tpg * (N / BN);
   if (nblk > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((conv1x1_mfma_kernel<BM, BN, BT, PRO, EPI>), dim3((unsigned)nblk), dim3(CV_THREADS), 0, st, (const __hip_bfloat16*)x,
+  hipLaunchKernelGGL((conv1x1_mfma_kernel<BM, BN, BT, PRO, EPI, DEEP>), dim3((unsigned)nblk), dim3(CV_THREADS), 0, st, (const __hip_bfloat16*)x,
                      (const __hip_bfloat16*)w, (__hip_bfloat16*)y, ws, Mg, K, N, tpg, (int)nblk, geom, fz);
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }
@@ -489,12 +518,18 @@ static int cv_dispatch(const void* x, const void* w, void* y, float* ws, long lo
                        const CvFuse& fz) {
   const long long Mg = M / G;
   ConvTile t = cv_pick_tile(Mg, G, N);
+  const bool deep = K >= 3 * CV_BK;
   if constexpr (PRO == 2) {      // its prologue coefficients + the transposed weight stage leave no room for two 128 x 128 blocks per CU
     if (t.bm == 128 && t.bn == 128) t.bn = 64;
   } else
-    if (t.bm == 128 && t.bn == 128) return cv_launch<128, 128, BT, PRO, EPI>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
-  if (t.bm == 128 && t.bn == 64) return cv_launch<128, 64, BT, PRO, EPI>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
-  return cv_launch<64, 64, BT, PRO, EPI>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+    if (t.bm == 128 && t.bn == 128) return cv_launch<128, 128, BT, PRO, EPI, false>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+  if (t.bm == 128 && t.bn == 64) {
+    if constexpr (PRO == 0)
+      if (deep) return cv_launch<128, 64, BT, PRO, EPI, true>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+    return cv_launch<128, 64, BT, PRO, EPI, false>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+  }
+  if (deep) return cv_launch<64, 64, BT, PRO, EPI, true>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
+  return cv_launch<64, 64, BT, PRO, EPI, false>(x, w, y, ws, Mg, G, K, N, geom, st, fz);
 }
 
 }  // namespace td
