@@ -287,6 +287,17 @@ int td_conv1x1_fwd(const void* x, const void* w, long long M, int groups, int K,
  *   y [B, Ho, Wo, N] bf16; Cin % 8 == 0, N % 64 == 0. */
 int td_conv3x3_fwd(const void* x, const void* w, int B, int groups, int Hi, int Wi, int Cin, int N, int stride, int pad, void* y,
                    float* stat_partials, td_stream_t stream);
+/* Weight gradient of a 3x3 stride-1 convolution (zero padding `pad` = 1: conv2 of the ResNet blocks, mono/model/mono_fm_joint/resnet.py:
+ * 30-49, 57-58; `pad` = 0 on a pre-padded input: Conv3x3 = ReflectionPad2d(1) + conv, mono/model/mono_fm_joint/layers.py:171-184):
+ *   dW[n, ky, kx, c] = sum_(b,ho,wo) dY[b, ho, wo, n] * X[b, ho + ky - pad, wo + kx - pad, c]
+ *   dy [B, Ho, Wo, N], x [B, Ho + 2 - 2 pad, Wo + 2 - 2 pad, C] bf16 channels-last; dw [N, 3, 3, C] (the memory of a channels-last
+ *   [N, C, 3, 3] weight) in bf16 or f32 (dw_dtype); C % 64 == N % 64 == 0, Wo >= 20, Ho >= 4.
+ * MFMA over the pixel index like td_conv1x1_wgrad, nine taps per staged tile, fp32 slabs per row range added in a fixed order
+ * (deterministic; MIOpen's split-K kernels accumulate with atomics into a zero-filled fp32 workspace and cast afterwards).
+ *   workspace: td_conv3x3_wgrad_workspace_floats(B, Ho, Wo, C, N) floats. */
+long long td_conv3x3_wgrad_workspace_floats(int B, int Ho, int Wo, int C, int N);
+int td_conv3x3_wgrad(const void* dy, const void* x, int B, int Ho, int Wo, int C, int N, int pad, int dw_dtype, void* dw,
+                     float* workspace, td_stream_t stream);
 long long td_conv1x1_wgrad_workspace_floats(long long M, int K, int N);
 int td_conv1x1_wgrad(const void* dy, const void* x, long long M, int K, int N, int Hi, int Wi, int stride, int dw_dtype, void* dw,
                      float* workspace, td_stream_t stream);

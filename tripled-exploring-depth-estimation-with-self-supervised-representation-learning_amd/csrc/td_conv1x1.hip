@@ -492,6 +492,16 @@ __global__ __launch_bounds__(TD_THREADS) void conv1x1_wgrad_reduce_kernel(const 
   }
 }
 
+// dW = ordered sum of P fp32 slabs of NK elements, rounded once to the weight's dtype (shared with td_conv3x3_wgrad.hip)
+int cv_wgrad_reduce(const float* part, int P, long long NK, int dw_dtype, void* dw, hipStream_t st) {
+  const unsigned blocks = (unsigned)((NK / 4 + 15) / 16);
+  if (dw_dtype == TD_DTYPE_BF16)
+    hipLaunchKernelGGL((conv1x1_wgrad_reduce_kernel<__hip_bfloat16>), dim3(blocks), dim3(TD_THREADS), 0, st, part, P, NK, (__hip_bfloat16*)dw);
+  else
+    hipLaunchKernelGGL((conv1x1_wgrad_reduce_kernel<float>), dim3(blocks), dim3(TD_THREADS), 0, st, part, P, NK, (float*)dw);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
 static inline int wg_splits(long long M, int K, int N) {
   const long long tiles = (long long)(N / WG_T) * (K / WG_T);
   long long p = (768 + tiles - 1) / tiles;                // 3 workgroups per CU = what its LDS holds at once (768 / 512 / 1024: 355 / 377 / 396 us over the probe's shapes)

@@ -56,6 +56,8 @@ SIGNATURES = {
     "td_conv1x1_stat_rows": (_I, [ctypes.c_longlong, _I, _I]),
     "td_conv1x1_fwd": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_conv3x3_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "td_conv3x3_wgrad_workspace_floats": (ctypes.c_longlong, [_I, _I, _I, _I, _I]),
+    "td_conv3x3_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_conv1x1_wgrad_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _I]),
     "td_conv1x1_wgrad": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_bn_fwd_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _I, _P, _P, _P, _P]),
