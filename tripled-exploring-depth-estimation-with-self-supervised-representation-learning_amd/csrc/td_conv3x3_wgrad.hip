@@ -63,15 +63,17 @@ __global__ __launch_bounds__(W3_THREADS, 2) void conv3x3_wgrad_kernel(
   const int Lb = cv_xcd_tile(blockIdx.x, gridDim.x);
   const int nt = Lb % tiles_n, ct = (Lb / tiles_n) % tiles_c, sp = Lb / (tiles_n * tiles_c);
   const int n0 = nt * W3_T, c0 = ct * W3_T;
-  const long long m_lo = (long long)sp * rows_per_split;
-  const long long m_hi = (m_lo + rows_per_split < M) ? m_lo + rows_per_split : M;
-  const int nstage = (int)((m_hi - m_lo + W3_T - 1) / W3_T);
+  // pixel indices fit 32 bits (checked by the entry point); only the final element offsets are 64-bit
+  const int Mi = (int)M;
+  const int m_lo = sp * rows_per_split;
+  const int m_hi = (m_lo + rows_per_split < Mi) ? m_lo + rows_per_split : Mi;
+  const int nstage = (m_hi - m_lo + W3_T - 1) / W3_T, last = nstage - 1;
   const int HoWo = Ho * Wo;
 
-  // ---- staging registers (named: see td_conv1x1.hip) ----
+  // ---- staging registers (named: see td_conv1x1.hip); two sets: the loads run TWO stages ahead of the arithmetic (a stage's
+  // MFMAs take ~0.3 us, a load round trip 1.5-2.5 us, and the 166 registers leave one block per CU to hide it) ----
   const int lc = tid & 7, lr = tid >> 3;
-  uint4 ry0, rx0, rx1, rx2, rx3;
-  // one band chunk: entry e = tid + 256 i -> (ky, position j, 16-byte chunk)
+  // this thread's (up to) four band chunks: entry e = tid + 512 i -> (ky, position j, 16-byte chunk), fixed for the whole kernel
   auto load_x = [&](int e, int b0, int ho0, int wo0) -> uint4 {
     if (e >= W3_XCHUNKS) return make_uint4(0, 0, 0, 0);
     const int ky = e / (W3_SPAN * 8), rem = e - ky * (W3_SPAN * 8), j = rem >> 3, ch = rem & 7;
@@ -84,24 +86,26 @@ __global__ __launch_bounds__(W3_THREADS, 2) void conv3x3_wgrad_kernel(
     if (ho >= Ho) { ho -= Ho; b += 1; }
     if (ho >= Ho) { ho -= Ho; b += 1; }
     const int hi = ho + ky - PAD, wi = v - PAD;         // PAD 1: v == 0 is the zero slot (wi = -1)
-    const bool ok = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi && ((long long)b * HoWo + (long long)ho * Wo) < M;
-    const long long q = ((long long)b * Hi + (ok ? hi : 0)) * Wi + (ok ? wi : 0);
-    const uint4 val = *reinterpret_cast<const uint4*>(x + (ok ? q : 0) * (long long)C + c0 + ch * 8);
+    const bool ok = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi && (b * HoWo + ho * Wo) < Mi;
+    const int q = ok ? (b * Hi + hi) * Wi + wi : 0;
+    const uint4 val = *reinterpret_cast<const uint4*>(x + (long long)q * C + c0 + ch * 8);
     return w3_keep(ok, val);
   };
-#define W3_LOAD(st)                                                                                                  \
+#define W3_DECL(S) uint4 ry0##S, rx0##S, rx1##S, rx2##S, rx3##S;
+  W3_DECL(A)
+  W3_DECL(B)
+#define W3_LOAD(st, S)                                                                                               \
   {                                                                                                                  \
-    const long long r0_ = m_lo + (long long)(st) * W3_T;                                                             \
-    const long long ra_ = r0_ + lr;                                                                                  \
-    const long long rc_ = ra_ < M ? ra_ : M - 1;                                                                     \
-    ry0 = *reinterpret_cast<const uint4*>(dy + rc_ * N + n0 + lc * 8);                                               \
-    ry0 = w3_keep(ra_ < m_hi, ry0);                                                                                  \
-    const long long rq_ = r0_ < M ? r0_ : M - 1;                                                                     \
-    const int b0_ = (int)(rq_ / HoWo), rem_ = (int)(rq_ - (long long)b0_ * HoWo), ho0_ = rem_ / Wo, wo0_ = rem_ - ho0_ * Wo; \
-    rx0 = load_x(tid, b0_, ho0_, wo0_);                                                                              \
-    rx1 = load_x(tid + 512, b0_, ho0_, wo0_);                                                                        \
-    rx2 = load_x(tid + 1024, b0_, ho0_, wo0_);                                                                       \
-    rx3 = load_x(tid + 1536, b0_, ho0_, wo0_);                                                                       \
+    const int r0_ = m_lo + (st) * W3_T;                                                                              \
+    const int ra_ = r0_ + lr;                                                                                        \
+    ry0##S = *reinterpret_cast<const uint4*>(dy + (long long)(ra_ < Mi ? ra_ : Mi - 1) * N + n0 + lc * 8);           \
+    ry0##S = w3_keep(ra_ < m_hi, ry0##S);                                                                            \
+    const int rq_ = r0_ < Mi ? r0_ : Mi - 1;                                                                         \
+    const int b0_ = rq_ / HoWo, rem_ = rq_ - b0_ * HoWo, ho0_ = rem_ / Wo, wo0_ = rem_ - ho0_ * Wo;                  \
+    rx0##S = load_x(tid, b0_, ho0_, wo0_);                                                                           \
+    rx1##S = load_x(tid + 512, b0_, ho0_, wo0_);                                                                     \
+    rx2##S = load_x(tid + 1024, b0_, ho0_, wo0_);                                                                    \
+    rx3##S = load_x(tid + 1536, b0_, ho0_, wo0_);                                                                    \
   }
   auto store_x = [&](int e, uint4 v) {
     if (e < W3_XCHUNKS) {
@@ -109,10 +113,10 @@ __global__ __launch_bounds__(W3_THREADS, 2) void conv3x3_wgrad_kernel(
       *reinterpret_cast<uint4*>(lds + W3_DY_BYTES + ky * W3_BAND_BYTES + j * W3_PITCH + ch * 16) = v;
     }
   };
-#define W3_WRITE()                                                                       \
+#define W3_WRITE(S)                                                                      \
   {                                                                                      \
-    *reinterpret_cast<uint4*>(lds + lr * W3_PITCH + lc * 16) = ry0;                      \
-    store_x(tid, rx0); store_x(tid + 512, rx1); store_x(tid + 1024, rx2); store_x(tid + 1536, rx3); \
+    *reinterpret_cast<uint4*>(lds + lr * W3_PITCH + lc * 16) = ry0##S;                   \
+    store_x(tid, rx0##S); store_x(tid + 512, rx1##S); store_x(tid + 1024, rx2##S); store_x(tid + 1536, rx3##S); \
   }
 
   cv_f32x16 acc[5];
@@ -125,20 +129,14 @@ __global__ __launch_bounds__(W3_THREADS, 2) void conv3x3_wgrad_kernel(
   const int fg = lane >> 4, fi = lane & 15;
   const int frow = 8 * (fg >> 1) + (fi >> 2), fcol = (16 * (fg & 1) + 4 * (fi & 3)) * 2;
 
-  W3_LOAD(0)
-  W3_WRITE()
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int nx = st + 1 < nstage ? st + 1 : st;         // branch-free prefetch: past the end the last stage is re-read (not used)
-    W3_LOAD(nx)
-    const long long r0 = m_lo + (long long)st * W3_T;
-    const int wo0 = (int)(r0 % Wo);
+  // one stage out of LDS: k-step outermost (one dY fragment live at a time), this wave's (up to) five independent accumulators
+  auto stage_mfma = [&](int st) {
+    const int wo0 = (m_lo + st * W3_T) % Wo;
     auto band_off = [&](int d) {          // byte offset of pixel row d of the stage inside a band: position d + G k(d)
       const int t = wo0 + d;
       const int k = (t >= Wo) + (t >= 2 * Wo) + (t >= 3 * Wo) + (t >= 4 * Wo);
       return (d + G * k) * W3_PITCH + fcol;
     };
-    // k-step outermost: one dY fragment live at a time, this wave's (up to) five independent accumulators behind it
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned char* p = lds + (16 * ks + frow) * W3_PITCH + (wn * 32) * 2 + fcol;
@@ -155,12 +153,32 @@ __global__ __launch_bounds__(W3_THREADS, 2) void conv3x3_wgrad_kernel(
         }
       }
     }
+  };
+
+  // branch-free prefetch (a conditional load makes the waitcnt pass drain the queue at the join): past the end the last stage is
+  // re-read and never used
+  W3_LOAD(0, A)
+  W3_LOAD(last < 1 ? last : 1, B)
+  W3_WRITE(A)
+  __syncthreads();
+  for (int st = 0; st < nstage; st += 2) {
+    W3_LOAD(st + 2 < last ? st + 2 : last, A)
+    __builtin_amdgcn_sched_barrier(0);
+    stage_mfma(st);
     __syncthreads();            // every wave has read this stage
-    W3_WRITE()
+    W3_WRITE(B)
+    __syncthreads();
+    if (st + 1 >= nstage) break;
+    W3_LOAD(st + 3 < last ? st + 3 : last, B)
+    __builtin_amdgcn_sched_barrier(0);
+    stage_mfma(st + 1);
+    __syncthreads();
+    W3_WRITE(A)
     __syncthreads();
   }
 #undef W3_LOAD
 #undef W3_WRITE
+#undef W3_DECL
   // D[i = n][j = c]: lane -> c = c0 + 32 wc + (lane & 31), register r -> n = n0 + 32 wn + (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
   // slab layout = the weight's memory [N][3][3][C]
   float* out = part + (size_t)sp * N * 9 * C;
@@ -183,9 +201,9 @@ int cv_wgrad_reduce(const float* part, int P, long long NK, int dw_dtype, void* 
 
 static inline int w3_splits(long long M, int C, int N) {
   const long long tiles = (long long)(N / W3_T) * (C / W3_T);
-  // ~128 workgroups: a stage is 36 MFMAs per wave (0.5 us) and every split costs a 4 N 9 C-byte slab written and re-read, so the
-  // grid is kept at one workgroup per two CUs (measured shapes: td_conv3x3_wgrad bench under profiles/r04)
-  long long p = (128 + tiles - 1) / tiles;
+  // one workgroup (8 waves) per CU: a stage is 36 MFMAs per wave pair and every split costs a 4 N 9 C-byte slab written and
+  // re-read (measured shapes: profiles/r04/conv3x3_wgrad_bench_*.txt)
+  long long p = (256 + tiles - 1) / tiles;
   const long long by_rows = (M + 4 * W3_T - 1) / (4 * W3_T);
   if (p > by_rows) p = by_rows;
   if (p > 512) p = 512;
@@ -209,7 +227,7 @@ extern "C" int td_conv3x3_wgrad(const void* dy, const void* x, int B, int Ho, in
   if (!w3_shape_ok(B, Ho, Wo, C, N, pad)) return TD_ERR_UNSUPPORTED;
   if (dw_dtype != TD_DTYPE_BF16 && dw_dtype != TD_DTYPE_F32) return TD_ERR_UNSUPPORTED;
   const long long M = (long long)B * Ho * Wo;
-  if (M * (long long)(C > N ? C : N) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  if (M >= (1ll << 31) - 128 || M * (long long)(C > N ? C : N) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int P = td::w3_splits(M, C, N);
   long long rps = (M + P - 1) / P;

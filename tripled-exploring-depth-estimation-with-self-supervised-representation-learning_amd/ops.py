@@ -505,6 +505,25 @@ def conv1x1_bn_act(x, w, weight, bias, running_mean, running_var, momentum, eps,
     return _Conv1x1BatchNormAct.apply(x, w, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, stride)
 
 
+def conv3x3_wgrad_wins(B, Ho, Wo, C, N, stride):
+    """Dispatch table of td_conv3x3_wgrad, from profiles/r04/conv3x3_wgrad_bench_v2.txt: the kernel beats MIOpen's weight
+    gradient (its zero-fill and cast passes included) on the 64-channel maps of 48 x 160 and larger; everywhere else MIOpen is
+    20-45 % faster and keeps the layer."""
+    return stride == 1 and C == 64 and N == 64 and Wo >= 160 and Ho >= 48 and B * Ho * Wo < (1 << 31) - 128
+
+
+def conv3x3_wgrad(dy, x, w, pad):
+    """dW of a 3x3 stride-1 convolution (td_conv3x3_wgrad): dy [B,N,Ho,Wo], x [B,C,Hi,Wi] bf16 channels_last -> like w."""
+    lib = native.load()
+    B, N, Ho, Wo = dy.shape
+    C = x.shape[1]
+    dw = torch.empty_like(w, memory_format=torch.channels_last)
+    ws = torch.empty(lib.td_conv3x3_wgrad_workspace_floats(B, Ho, Wo, C, N), device=x.device, dtype=torch.float32)
+    native.check(lib.td_conv3x3_wgrad(_raw(dy), _raw(x), B, Ho, Wo, C, N, pad, native.DTYPE_CODES[w.dtype], _raw(dw), native.ptr(ws),
+                                      native.stream()), "td_conv3x3_wgrad")
+    return dw
+
+
 class BnState:
     """What a BatchNorm layer contributes to a fused block: affine parameters are passed as tensors (autograd), the rest here."""
     __slots__ = ("running_mean", "running_var", "momentum", "eps")
@@ -649,9 +668,13 @@ class _Bottleneck(torch.autograd.Function):
         native.check(lib.td_bn_bwd_from_partials(_raw(da2), _raw(z2), None, BF, native.ptr(g2), native.ptr(b2), native.ptr(mean2),
                                                  native.ptr(invstd2), 1, M2, groups, c, native.ptr(q2), S2, _raw(dz2), None,
                                                  native.ptr(dg2), native.ptr(db2), strm), "td_bn_bwd_from_partials")
-        # conv2: MIOpen
+        # conv2: MIOpen -- except the weight gradient of the shapes where the hand-written 3x3 kernel is ahead of MIOpen's
+        # split-K kernel + its zero-fill / cast passes (profiles/r04/conv3x3_wgrad_bench_v2.txt: 64 -> 64 channels at 48 x 160)
+        own_wgrad = conv3x3_wgrad_wins(Nb, Ho, Wo, c, c, stride)
         da1, dw2, _ = torch.ops.aten.convolution_backward(dz2, a1, w2, None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1,
-                                                          [True, True, False])
+                                                          [True, not own_wgrad, False])
+        if own_wgrad:
+            dw2 = conv3x3_wgrad(dz2, a1, w2, pad=1)
         if not da1.is_contiguous(memory_format=torch.channels_last):
             da1 = da1.contiguous(memory_format=torch.channels_last)
         # bn1 statistics pass; its dx rides on conv1's data gradient
