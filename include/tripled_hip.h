@@ -307,6 +307,17 @@ int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, cons
                             float* save_invstd, td_stream_t stream);
 
 /*
+ * Optimiser step of a flat fp32 parameter buffer in one pass: the gradient scale of torch.nn.utils.clip_grad_norm_ (total_norm: device
+ * scalar, the 2-norm of grad, or NULL for no clipping), torch.optim.Adam's update (weight_decay 0, no amsgrad; `step` = device scalar
+ * holding the 1-based step count, lr from the device scalar lr_dev or, when NULL, lr_host) and the bf16 working copy of the first
+ * n_lowp parameters.  Replaces optimizer_config.grad_clip + optimizer.step() of the training hook (mono/core/utils/dist_utils.py:54-60)
+ * on the flat store of tripled_amd/flat_amp.py.  n % 4 == 0, n_lowp % 4 == 0.
+ */
+int td_adam_flat(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, void* lowp, long long n, long long n_lowp,
+                 const float* step, const float* lr_dev, float lr_host, float beta1, float beta2, float eps, const float* total_norm,
+                 float max_norm, td_stream_t stream);
+
+/*
  * Fused forms of the bottleneck's 1x1 convolutions (round 4): the BatchNorm passes of the NEIGHBOURING layers ride on the GEMM's
  * operand staging and epilogue instead of being separate passes over the activations.  Reference: Bottleneck.forward,
  * mono/model/mono_fm_joint/resnet.py:66-86 (conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += identity -> relu)

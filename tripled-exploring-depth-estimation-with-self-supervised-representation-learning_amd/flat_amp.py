@@ -21,6 +21,7 @@ the plain step on one GPU and is what ``bench.py --gpus N`` (N > 1) uses between
 """
 import collections
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -267,11 +268,44 @@ class FlatMixedPrecision:
             if not self.use_avg:
                 chunk.div_(self.world)
 
+    def _fused_step_possible(self):
+        g = self.optimizer.param_groups[0]
+        return (self.flat_w.is_cuda and not os.environ.get("TD_NO_FUSED_ADAM") and g.get("weight_decay", 0) == 0
+                and not g.get("amsgrad", False) and not g.get("maximize", False) and self.flat_w.numel() % 4 == 0 and self.n_lp % 4 == 0
+                and (self.n_lp == 0 or self.flat_lp.dtype == torch.bfloat16))
+
+    def _adam_state(self):
+        """torch.optim.Adam's own state entry of the master parameter (created like torch's lazy init, so that checkpoints and a
+        later plain optimizer.step() see what they expect)."""
+        st = self.optimizer.state[self.master]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=self.flat_w.device)
+            st["exp_avg"] = torch.zeros_like(self.flat_w)
+            st["exp_avg_sq"] = torch.zeros_like(self.flat_w)
+        return st
+
     def step(self):
-        """clip_grad_norm_(max_norm, 2) + Adam on the flat buffers, then refresh the bf16 working copy."""
+        """clip_grad_norm_(max_norm, 2) + Adam on the flat buffers, then refresh the bf16 working copy.  On a HIP device the
+        gradient scale, the update and the cast are ONE pass (td_adam_flat, csrc/td_optim.hip: 30 B per parameter instead of
+        the ~50 B of ATen's scale / multi-tensor Adam / cast passes); elsewhere the same steps through torch."""
         total = None
         if self.max_norm is not None:
             total = torch.linalg.vector_norm(self.flat_g)
+        if self._fused_step_possible():
+            from . import native
+            lib = native.load()
+            st, grp = self._adam_state(), self.optimizer.param_groups[0]
+            st["step"] += 1
+            lr = grp["lr"]
+            native.check(lib.td_adam_flat(native.ptr(self.flat_w), native.ptr(self.flat_g), native.ptr(st["exp_avg"]),
+                                          native.ptr(st["exp_avg_sq"]), native.ptr(self.flat_lp) if self.n_lp else None,
+                                          self.flat_w.numel(), self.n_lp, native.ptr(st["step"]),
+                                          native.ptr(lr) if torch.is_tensor(lr) else None, 0.0 if torch.is_tensor(lr) else float(lr),
+                                          float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
+                                          native.ptr(total) if total is not None else None,
+                                          float(self.max_norm) if self.max_norm is not None else 0.0, native.stream()), "td_adam_flat")
+            return total
+        if total is not None:
             self.flat_g.mul_(torch.clamp(self.max_norm / (total + 1e-6), max=1.0))
         self.optimizer.step()
         if self.n_lp:

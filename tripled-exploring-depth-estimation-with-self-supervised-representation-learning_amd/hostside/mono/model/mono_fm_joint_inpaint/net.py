@@ -65,8 +65,9 @@ class mono_fm_joint_inpaint(mono_fm_joint):
         opt = self.opt
         res_img = outputs[("res_img", 0, scale)].float()
         size = list(res_img.shape[2:])
-        t_rs = F.interpolate(inputs[("color", 0, 0)], size, mode="bilinear", align_corners=False)
-        hole = 1 - F.interpolate(inputs[("mask", 0, 0)], size, mode="bilinear", align_corners=False)
+        # (at scale 0 the size is the input's own: bilinear resampling at the pixel centres is a bit-exact identity, skipped)
+        t_rs = resize_bilinear(inputs[("color", 0, 0)], size)
+        hole = 1 - resize_bilinear(inputs[("mask", 0, 0)], size)
         if res_img.is_cuda and size[0] >= 3 and size[1] >= 3:
             # fused HIP path: SSIM + L1 + masked sum in one streaming kernel (and one for the gradient);
             # the 3 mask channels weight the same per-pixel loss, so they collapse to one plane
