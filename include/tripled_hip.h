@@ -307,6 +307,21 @@ int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, cons
                             float* save_invstd, td_stream_t stream);
 
 /*
+ * Bias + activation behind a convolution and its adjoint with the bias gradient, on channels-last activations [M, C] (f32 or bf16,
+ * C % 8 == 0, C <= 256, 256 % (C / 8) == 0).  Replaces, around the decoders' convolutions (ConvBlock = Conv3x3 -> ELU,
+ * mono/model/mono_fm_joint/layers.py:143-155; F.leaky_relu(iconv / merge), mono/model/mono_fm_joint/depth_decoder.py:89-103): the bias
+ * add of the convolution, the activation, the activation's backward and the bias-gradient reduction of the convolution's backward.
+ *   act: 0 none, 1 ELU(alpha = 1), 2 leaky ReLU(0.01);  bias [C] f32 or bf16 (bias_dtype; NULL = no bias)
+ *   td_bias_act_fwd: a = act(y + bias)            (a may alias y)
+ *   td_bias_act_bwd: gy = g * act'(a) (from the RESULT a; gy may alias g; act 0: gy is not written, dbias = column sums of g),
+ *                    dbias [C] (nullable) = sum over rows of gy, deterministic; workspace: td_bias_act_workspace_floats(M, C) floats.
+ */
+long long td_bias_act_workspace_floats(long long M, int C);
+int td_bias_act_fwd(const void* y, const void* bias, int bias_dtype, int dtype, long long M, int C, int act, void* a, td_stream_t stream);
+int td_bias_act_bwd(const void* g, const void* a, int dtype, long long M, int C, int act, void* gy, void* dbias, int dbias_dtype,
+                    float* workspace, td_stream_t stream);
+
+/*
  * Optimiser step of a flat fp32 parameter buffer in one pass: the gradient scale of torch.nn.utils.clip_grad_norm_ (total_norm: device
  * scalar, the 2-norm of grad, or NULL for no clipping), torch.optim.Adam's update (weight_decay 0, no amsgrad; `step` = device scalar
  * holding the 1-based step count, lr from the device scalar lr_dev or, when NULL, lr_host) and the bf16 working copy of the first

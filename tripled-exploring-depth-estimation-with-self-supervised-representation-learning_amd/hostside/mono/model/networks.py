@@ -640,14 +640,33 @@ class _KeepChannels(torch.autograd.Function):
         return F.pad(g, (0, 0, 0, 0, 0, ctx.pad)), None
 
 
-def _conv2d_guarded(x, w, b):
-    """F.conv2d, except for the narrow (<= 16 channels) layers on inputs wider than 1024 columns: see _ConvImmediate."""
+FUSED_BIAS_ACT_OFF = bool(os.environ.get("TD_NO_FUSED_BIAS_ACT"))
+
+
+def _activate(y, act):
+    if act == "elu":
+        return F.elu(y, inplace=True)
+    if act == "leaky_relu":
+        return F.leaky_relu(y)
+    return y
+
+
+def _conv2d_guarded(x, w, b, act=None):
+    """act(F.conv2d(x, w, b)), act in (None, "elu", "leaky_relu").  Under bf16 autocast on channels-last HIP activations the bias,
+    the activation and their adjoints (incl. the bias gradient) are fused around MIOpen's convolution
+    (tripled_amd.ops.conv_bias_act).  The narrow (<= 16 channels) layers on inputs wider than 1024 columns keep _ConvImmediate."""
     if x.is_cuda and x.shape[1] <= 16 and w.shape[0] <= 16 and x.shape[3] > 1024 and torch.backends.cudnn.benchmark:
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda")
             x, w, b = x.to(dt), w.to(dt), (b.to(dt) if b is not None else None)
-        return _ConvImmediate.apply(x, w, b)
-    return F.conv2d(x, w, b)
+        return _activate(_ConvImmediate.apply(x, w, b), act)
+    if (act is not None or b is not None) and x.is_cuda and not FUSED_BIAS_ACT_OFF and torch.is_grad_enabled() \
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        wb = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        if _ops().conv_bias_act_supported(xb, wb, b, act):
+            return _ops().conv_bias_act(xb, wb, b, act)
+    return _activate(F.conv2d(x, w, b), act)
 
 
 class Conv3x3(nn.Module):
@@ -675,17 +694,19 @@ class Conv3x3(nn.Module):
             _fell_back("Conv3x3.pad", x)
         return self.pad(x)
 
-    def forward(self, x):
+    def forward(self, x, act=None):
+        """act(conv(pad(x))); ``act`` (None / "elu" / "leaky_relu") is the activation that follows this convolution in the
+        decoders -- handed in so that it can be fused with the bias (``_conv2d_guarded``)."""
         # bf16 (autocast) only: MIOpen's f32 NHWC backward-data path crashes for 8-channel outputs
         # (conv -n 2 -c 16 -H 98 -W 162 -k 8 -y 3 -x 3, ROCm 7.2), so f32 models keep the plain convolution
         low_precision = x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())
         if not low_precision or os.environ.get("TD_NO_CHANNEL_PAD"):
-            return self.conv(self._pad_input(x) if x.is_cuda else self.pad(x))
+            return _activate(self.conv(self._pad_input(x) if x.is_cuda else self.pad(x)), act)
         w, b = self.conv.weight, self.conv.bias
         cout, cin = w.shape[0], w.shape[1]
         cin_p, cout_p = _round8(cin), _round8(cout)
         if cin_p == cin and cout_p == cout and x.shape[1] == cin:
-            return _conv2d_guarded(self._pad_input(x), w, b)
+            return _conv2d_guarded(self._pad_input(x), w, b, act)
         if x.shape[1] == cin and cin_p != cin:               # caller did not pre-pad the channels
             x = torch.cat((x, x.new_zeros(x.shape[0], cin_p - cin, x.shape[2], x.shape[3])), 1)
         if x.shape[1] != cin_p:
@@ -695,12 +716,12 @@ class Conv3x3(nn.Module):
         w = F.pad(w, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
         if b is not None and cout_p != cout:
             b = F.pad(b, (0, cout_p - cout))
-        y = _conv2d_guarded(self._pad_input(x), w, b)
-        return _KeepChannels.apply(y, cout) if cout_p != cout else y
+        if cout_p != cout:
+            return _activate(_KeepChannels.apply(_conv2d_guarded(self._pad_input(x), w, b), cout), act)
+        return _conv2d_guarded(self._pad_input(x), w, b, act)
 
-
-    def forward_up(self, x):
-        """self(upsample(x)): x2 nearest + reflection pad in one HIP pass when the layout allows it (output channels
+    def forward_up(self, x, act=None):
+        """act(self(upsample(x))): x2 nearest + reflection pad in one HIP pass when the layout allows it (output channels
         padded to a multiple of 8 like forward(), e.g. the 1-channel disparity heads)."""
         w, b = self.conv.weight, self.conv.bias
         cout, cin = w.shape[0], w.shape[1]
@@ -713,10 +734,11 @@ class Conv3x3(nn.Module):
             if cout_p != cout:
                 w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
                 b = F.pad(b, (0, cout_p - cout)) if b is not None else None
-            y = _conv2d_guarded(_ops().up2_reflpad1(x), w, b)
-            return _KeepChannels.apply(y, cout) if cout_p != cout else y
+            if cout_p != cout:
+                return _activate(_KeepChannels.apply(_conv2d_guarded(_ops().up2_reflpad1(x), w, b), cout), act)
+            return _conv2d_guarded(_ops().up2_reflpad1(x), w, b, act)
         _fell_back("Conv3x3.forward_up", x)
-        return self.forward(upsample(x))
+        return self.forward(upsample(x), act)
 
 
 class Conv5x5(nn.Module):
@@ -736,11 +758,11 @@ class ConvBlock(nn.Module):
         self.nonlin = nn.ELU(inplace=True)
 
     def forward(self, x):
-        return self.nonlin(self.conv(x))
+        return self.conv(x, act="elu")          # self.nonlin = ELU(alpha 1), fused with the convolution's bias
 
     def forward_up(self, x):
         """self(upsample(x)) without materialising the up-sampled tensor (Conv3x3.forward_up)."""
-        return self.nonlin(self.conv.forward_up(x))
+        return self.conv.forward_up(x, act="elu")
 
 
 class CRPBlock(nn.Module):
@@ -834,9 +856,9 @@ class DepthDecoder(nn.Module):
         """Returns (stage output, disparity, deferred).  deferred = True: the stage output is still at HALF resolution --
         its x2 nearest up-sampling is folded into the consumers (the disparity head's pad here, the channel join of the
         next stage), so the up-sampled 256-channel map (189 MB at the last stage of C2) is never materialised."""
-        x = F.leaky_relu(getattr(self, "iconv%d" % i)(x))
+        x = getattr(self, "iconv%d" % i)(x, act="leaky_relu")
         x = getattr(self, "crp%d" % i)(x)
-        x = F.leaky_relu(getattr(self, "merge%d" % i)(x))
+        x = getattr(self, "merge%d" % i)(x, act="leaky_relu")
         head = getattr(self, "disp%d" % i)
         if self.use_shuffle:
             # the reference up-samples stage 1 with up2 (depth_decoder.py:105), kept as is

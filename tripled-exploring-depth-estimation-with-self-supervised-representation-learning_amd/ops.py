@@ -505,6 +505,64 @@ def conv1x1_bn_act(x, w, weight, bias, running_mean, running_var, momentum, eps,
     return _Conv1x1BatchNormAct.apply(x, w, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, stride)
 
 
+ACT_CODES = {None: 0, "elu": 1, "leaky_relu": 2}
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """act(conv2d(x, w) + b) for a stride-1 unpadded convolution (the decoders' Conv3x3 after its reflection pad): the
+    convolution through MIOpen WITHOUT its bias, then bias + activation in one in-place pass (td_bias_act_fwd); backward: the
+    activation's adjoint and the bias gradient in one pass (td_bias_act_bwd) in front of MIOpen's data / weight gradients.
+    Reference: ConvBlock (layers.py:143-155), depth_decoder.py:89-103."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        lib = native.load()
+        y = torch.ops.aten.convolution(x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        B, C, H, W = y.shape
+        native.check(lib.td_bias_act_fwd(_raw(y), _raw(b) if b is not None else None, native.DTYPE_CODES[b.dtype] if b is not None else 0,
+                                         native.DTYPE_CODES[y.dtype], B * H * W, C, ACT_CODES[act], _raw(y), native.stream()),
+                     "td_bias_act_fwd")
+        ctx.save_for_backward(x, w, y if act is not None else None, b)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        x, w, a, b = ctx.saved_tensors
+        B, C, H, W = g.shape
+        if g.dtype != w.dtype or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.to(w.dtype).contiguous(memory_format=torch.channels_last)
+        M = B * H * W
+        gy = torch.empty_like(g, memory_format=torch.channels_last) if ctx.act is not None else g
+        db = torch.empty_like(b) if b is not None and ctx.needs_input_grad[2] else None
+        ws = torch.empty(lib.td_bias_act_workspace_floats(M, C), device=g.device, dtype=torch.float32)
+        if ctx.act is not None or db is not None:
+            native.check(lib.td_bias_act_bwd(_raw(g), _raw(a) if a is not None else None, native.DTYPE_CODES[g.dtype], M, C,
+                                             ACT_CODES[ctx.act], _raw(gy) if ctx.act is not None else None,
+                                             _raw(db) if db is not None else None, native.DTYPE_CODES[db.dtype] if db is not None else 0,
+                                             native.ptr(ws), native.stream()), "td_bias_act_bwd")
+        dx, dw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, db, None
+
+
+def conv_bias_act_supported(x, w, b, act):
+    cout = w.shape[0]
+    return (act in ACT_CODES and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and x.is_contiguous(memory_format=torch.channels_last) and (b is None or b.dtype in native.DTYPE_CODES)
+            and 8 <= cout <= 256 and cout % 8 == 0 and 256 % (cout // 8) == 0 and x.shape[1] == w.shape[1])
+
+
+def conv_bias_act(x, w, b, act=None):
+    """act(F.conv2d(x, w, b)) (stride 1, no padding) with bias + activation and their adjoints fused (see _ConvBiasAct)."""
+    if not conv_bias_act_supported(x, w, b, act):
+        raise native.NativeLibraryError("conv_bias_act needs bf16 channels_last HIP tensors, Cout in {8, 16, 32, 64, 128, 256}")
+    return _ConvBiasAct.apply(x, w, b, act)
+
+
 def conv3x3_wgrad_wins(B, Ho, Wo, C, N, stride):
     """Dispatch table of td_conv3x3_wgrad, from profiles/r04/conv3x3_wgrad_bench_v2.txt: the kernel beats MIOpen's weight
     gradient (its zero-fill and cast passes included) on the 64-channel maps of 48 x 160 and larger; everywhere else MIOpen is
