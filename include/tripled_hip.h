@@ -468,8 +468,10 @@ int td_up2_reflpad1_bwd(const void* grad_out, int dtype, int N, int H, int W, in
  *   argmin       [B,h,w] uint8 (out: which source frame gives the minimum)
  *   partial      [td_featwarp_num_blocks] per-block sums of min_f mean_c sqrt((tgt - warp_f)^2 + 1e-6)
  * Backward (gradient of gscale[0] * inv_count * sum(partial)):
- *   d_tgt [B,h,w,C] (feature dtype), d_src[i] [B,h,w,C] f32 -- MUST be zero-filled by the caller, the
- *   scatter accumulates with atomics --, d_up [B,h,w] (w.r.t. the up-sampled disparity; td_upsample_adjoint),
+ *   d_tgt [B,h,w,C] (feature dtype), d_src[i] [B,h,w,C] int32 fixed-point accumulators -- MUST be zero-filled by the caller; the
+ *   scatter adds contributions rounded to multiples of |gscale| * inv_count / C / 2^14 with integer atomics (order-independent,
+ *   bit-reproducible); td_featwarp_dsrc_finish turns them into the gradient in the feature dtype --,
+ *   d_up [B,h,w] (w.r.t. the up-sampled disparity; td_upsample_adjoint),
  *   dP_partial [td_featwarp_num_blocks, n_src*12] (td_reduce_partials with blocks_per_sample =
  *   td_featwarp_num_blocks / B).
  */
@@ -480,8 +482,12 @@ int td_featwarp_fwd(const void* tgt, const void* const* src, int n_src, int dtyp
 int td_featwarp_bwd(const void* tgt, const void* const* src, int n_src, int dtype, const float* disp,
                     const float* P, const float* invK, const uint8_t* argmin, const float* gscale,
                     float inv_count, int B, int h, int w, int C, int hs, int ws, float min_depth,
-                    float max_depth, void* d_tgt, float* const* d_src, float* d_up, float* dP_partial,
+                    float max_depth, void* d_tgt, int* const* d_src, float* d_up, float* dP_partial,
                     td_stream_t stream);
+/* out[i] = acc[i] * |gscale[0]| * inv_count / C / 2^14 (n elements, n % 8 == 0; dtype f32 or bf16): the scatter's accumulators
+ * -> d/d(source features). */
+int td_featwarp_dsrc_finish(const int* acc, const float* gscale, float inv_count, int C, long long n, int dtype, void* out,
+                            td_stream_t stream);
 /* dP[i,b,:] = sum over the blocks_per_sample consecutive rows of partial[., n_src*12] that belong to sample b. */
 int td_reduce_partials(const float* partial, int n_src, int B, int blocks_per_sample, float* dP,
                        td_stream_t stream);

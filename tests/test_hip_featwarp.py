@@ -81,3 +81,36 @@ def test_feature_metric(dtype, B, C, h, w, hs, ws):
     for a, r in zip(Tg, Tr):
         # (full size: the pose gradient sums the steep-regime elements of 10^5..10^6 pixels)
         assert rel_err(a.grad, r.grad) < (max(gt, 5e-3) if w <= 64 else 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backward_is_bit_reproducible(dtype):
+    """The source-feature gradient is a scatter with many contributions per element (here three near-identical frames warp onto
+    each other and a coarse disparity makes neighbouring pixels land on the same source texels).  Since round 4 it accumulates
+    in int32 fixed point (integer atomics commute), so two launches give the same bits -- with float atomics they did not --
+    (the quantum is 2^-14 of the largest possible term, below the bf16 rounding of the result; the full-size cases of
+    test_feature_metric pile thousands of border-clamped contributions onto corner texels without wrapping)."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, C, h, w = 4, 64, 48, 160
+    base = F.avg_pool2d(torch.randn(B, C, h + 4, w + 4, generator=g), 3, 1, 1) * 4.0
+    tgt = base[:, :, 2:2 + h, 2:2 + w].contiguous()
+    srcs = [base[:, :, 2:2 + h, 1:1 + w].contiguous(), base[:, :, 3:3 + h, 2:2 + w].contiguous()]
+    K, invK = kitti_K(B, h, w)
+    Ts = random_poses(g, B, rot=0.01, trans=0.3)
+    disp = (0.2 + 0.6 * smooth_image(g, B, 1, 8, 8)[:, :, :6, :20]).contiguous()
+    cl = lambda t: t.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    P = torch.stack([torch.matmul(K.cuda(), T.cuda())[:, :3, :] for T in Ts], 0)
+    grads = []
+    for _ in range(3):
+        tg, sg = cl(tgt).requires_grad_(True), [cl(s).requires_grad_(True) for s in srcs]
+        dg = disp.cuda().requires_grad_(True)
+        loss, _ = ops.feature_warp_min_loss(tg, sg, dg, P, invK.cuda(), 0.1, 100.0)
+        (loss * 3.0).backward()
+        torch.cuda.synchronize()
+        grads.append([tg.grad.clone(), dg.grad.clone()] + [s.grad.clone() for s in sg])
+    for other in grads[1:]:
+        for a, b in zip(grads[0], other):
+            assert torch.equal(a, b)
+    assert all(float(s.abs().max()) > 0 for s in grads[0][2:])

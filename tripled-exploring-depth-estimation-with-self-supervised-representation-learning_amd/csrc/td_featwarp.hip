@@ -7,8 +7,15 @@
 // Layout: features channels-last (NHWC, bf16 or f32).  8 lanes cooperate on one pixel, 8 channels each
 // (16-byte loads), so a wave covers 8 pixels x 64 channels per chunk.
 // Backward: d/d(disparity), d/dP, d/d(target features) are written directly; d/d(source features) is a
-// true scatter (a source pixel may receive from any target pixel) and uses f32 atomics, issued as
-// 256-byte contiguous wave-instructions (one pixel x 64 channels) through a small LDS transpose.
+// true scatter (a source pixel may receive from any target pixel).  It accumulates with INTEGER atomics on a fixed-point image of
+// the contributions (round 4: float atomics made this the one hand-written kernel whose result depended on the arrival order):
+// every contribution is bounded by |g| = |gscale| * inv_count / C (robust-L1 slope <= 1, bilinear weight <= 1), so it is
+// rounded to a multiple of |g| / 2^14 and added as int32 -- integer addition is associative, the sum is bit-reproducible, the
+// quantum is 6e-5 of the largest possible term (the result is rounded to bf16, 4e-3, afterwards) and 131072 full-size terms fit
+// in one texel: border padding sends EVERY out-of-range sample to the border texels, so a corner can collect a large part of a
+// feature map (160 x 512 = 81920 pixels at the largest configuration); 2^20 wrapped there.
+// The atomics are issued as 256-byte contiguous wave-instructions (one pixel x 64 channels) through a small LDS transpose;
+// td_featwarp_dsrc_finish scales the accumulators back into the feature dtype.
 #include <hip/hip_bf16.h>
 
 #include "td_common.h"
@@ -29,7 +36,7 @@ struct FeatWarpArgs {
   const float* gscale;
   float inv_count;
   T* d_tgt;              // [B,h,w,C]
-  float* d_src[NS];      // [B,h,w,C] f32, zero-initialised by the caller (atomic accumulation)
+  int* d_src[NS];        // [B,h,w,C] int32 fixed point (units of |g| / 2^14), zero-initialised by the caller
   float* d_up;           // [B,h,w]
   float* dP_partial;     // [blocks, NS*12]
   int B, h, w, C, hs, ws;
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(TD_THREADS) void featwarp_bwd_kernel(const FeatWarp
   const T* tb = a.tgt + (size_t)pix * C;
   // every lane needs its own frame's base pointers (frames differ between the pixels of a wave)
   const T* sb = a.src[0] + (size_t)b * h * w * C;
-  float* db = a.d_src[0] + (size_t)b * h * w * C;
+  int* db = a.d_src[0] + (size_t)b * h * w * C;
+  const float gabs = fabsf(a.gscale[0] * a.inv_count / (float)C);
+  const float qscale = gabs > 0.f ? 16384.f / gabs : 0.f;          // launch-uniform
 #pragma unroll
   for (int f = 1; f < NS; ++f)
     if (f_sel == f) { sb = a.src[f] + (size_t)b * h * w * C; db = a.d_src[f] + (size_t)b * h * w * C; }
@@ -176,13 +185,13 @@ __global__ __launch_bounds__(TD_THREADS) void featwarp_bwd_kernel(const FeatWarp
       const float wnw = __shfl(t.nw, src_lane, 64), wne = __shfl(t.ne, src_lane, 64);
       const float wsw = __shfl(t.sw, src_lane, 64), wse = __shfl(t.se, src_lane, 64);
       const unsigned long long dbp = __shfl((unsigned long long)db, src_lane, 64);
-      float* dbase = reinterpret_cast<float*>(dbp) + c0 + lane;
-      const float v = s_gl[wid][p][lane];
+      int* dbase = reinterpret_cast<int*>(dbp) + c0 + lane;
+      const float v = s_gl[wid][p][lane] * qscale;
       // ATen skips taps outside the image; their weight is exactly 0 here, adding 0 is harmless
-      atomicAdd(dbase + ((size_t)ty0 * w + tx0) * C, v * wnw);
-      atomicAdd(dbase + ((size_t)ty0 * w + tx1) * C, v * wne);
-      atomicAdd(dbase + ((size_t)ty1 * w + tx0) * C, v * wsw);
-      atomicAdd(dbase + ((size_t)ty1 * w + tx1) * C, v * wse);
+      atomicAdd(dbase + ((size_t)ty0 * w + tx0) * C, __float2int_rn(v * wnw));
+      atomicAdd(dbase + ((size_t)ty0 * w + tx1) * C, __float2int_rn(v * wne));
+      atomicAdd(dbase + ((size_t)ty1 * w + tx0) * C, __float2int_rn(v * wsw));
+      atomicAdd(dbase + ((size_t)ty1 * w + tx1) * C, __float2int_rn(v * wse));
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -225,6 +234,20 @@ __global__ __launch_bounds__(TD_THREADS) void featwarp_bwd_kernel(const FeatWarp
   }
 }
 
+// accumulators -> gradient in the feature dtype: d_src[i] = acc[i] * |g| / 2^14
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void featwarp_dsrc_finish_kernel(const int* __restrict__ acc, const float* __restrict__ gscale,
+                                                                          float inv_count_over_C, long long nvec, T* __restrict__ out) {
+  const float unit = fabsf(gscale[0] * inv_count_over_C) * (1.f / 16384.f);
+  const long long stride = (long long)gridDim.x * TD_THREADS;
+  for (long long i = (long long)blockIdx.x * TD_THREADS + threadIdx.x; i < nvec; i += stride) {
+    const int4 a0 = reinterpret_cast<const int4*>(acc)[2 * i], a1 = reinterpret_cast<const int4*>(acc)[2 * i + 1];
+    const float v[8] = {(float)a0.x * unit, (float)a0.y * unit, (float)a0.z * unit, (float)a0.w * unit,
+                        (float)a1.x * unit, (float)a1.y * unit, (float)a1.z * unit, (float)a1.w * unit};
+    store8(out + i * 8, v);
+  }
+}
+
 // blocks never straddle two samples: the grid is laid out per sample (gridDim = B * blocks_per_sample)
 template <typename T, int NS>
 static int launch_featwarp(bool fwd, FeatWarpArgs<T, NS>& a, hipStream_t st) {
@@ -237,7 +260,7 @@ static int launch_featwarp(bool fwd, FeatWarpArgs<T, NS>& a, hipStream_t st) {
 template <typename T, int NS>
 static int run_featwarp(bool fwd, const void* tgt, const void* const* src, const float* disp, const float* P,
                         const float* invK, uint8_t* argmin, float* partial, const float* gscale, float inv_count,
-                        void* d_tgt, float* const* d_src, float* d_up, float* dP_partial, int B, int h, int w, int C,
+                        void* d_tgt, int* const* d_src, float* d_up, float* dP_partial, int B, int h, int w, int C,
                         int hs, int ws, float min_depth, float max_depth, hipStream_t st) {
   FeatWarpArgs<T, NS> a;
   a.tgt = (const T*)tgt;
@@ -259,7 +282,7 @@ extern "C" int td_featwarp_num_blocks(int B, int h, int w) {
 
 static int featwarp_dispatch(bool fwd, const void* tgt, const void* const* src, int n_src, int dtype, const float* disp,
                              const float* P, const float* invK, uint8_t* argmin, float* partial, const float* gscale,
-                             float inv_count, void* d_tgt, float* const* d_src, float* d_up, float* dP_partial, int B,
+                             float inv_count, void* d_tgt, int* const* d_src, float* d_up, float* dP_partial, int B,
                              int h, int w, int C, int hs, int ws, float min_depth, float max_depth, td_stream_t stream) {
   if (!tgt || !src || !disp || !P || !invK || !argmin || n_src < 1 || n_src > 2 || B <= 0) return TD_ERR_BAD_ARG;
   if (C % 64 != 0 || h < 2 || w < 2 || hs > h || ws > w) return TD_ERR_UNSUPPORTED;
@@ -283,10 +306,26 @@ extern "C" int td_featwarp_fwd(const void* tgt, const void* const* src, int n_sr
 extern "C" int td_featwarp_bwd(const void* tgt, const void* const* src, int n_src, int dtype, const float* disp,
                                const float* P, const float* invK, const uint8_t* argmin, const float* gscale,
                                float inv_count, int B, int h, int w, int C, int hs, int ws, float min_depth,
-                               float max_depth, void* d_tgt, float* const* d_src, float* d_up, float* dP_partial,
+                               float max_depth, void* d_tgt, int* const* d_src, float* d_up, float* dP_partial,
                                td_stream_t stream) {
   if (!gscale || !d_tgt || !d_src || !d_up || !dP_partial) return TD_ERR_BAD_ARG;
   for (int i = 0; i < n_src; ++i) if (!d_src[i]) return TD_ERR_BAD_ARG;
   return featwarp_dispatch(false, tgt, src, n_src, dtype, disp, P, invK, const_cast<uint8_t*>(argmin), nullptr, gscale,
                            inv_count, d_tgt, d_src, d_up, dP_partial, B, h, w, C, hs, ws, min_depth, max_depth, stream);
+}
+
+extern "C" int td_featwarp_dsrc_finish(const int* acc, const float* gscale, float inv_count, int C, long long n, int dtype, void* out,
+                                       td_stream_t stream) {
+  if (!acc || !gscale || !out || n <= 0 || C <= 0) return TD_ERR_BAD_ARG;
+  if (n % 8 != 0 || (dtype != TD_DTYPE_BF16 && dtype != TD_DTYPE_F32)) return TD_ERR_UNSUPPORTED;
+  const long long nvec = n / 8;
+  long long blocks = (nvec + TD_THREADS * 4 - 1) / (TD_THREADS * 4);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == TD_DTYPE_BF16)
+    hipLaunchKernelGGL((td::featwarp_dsrc_finish_kernel<__hip_bfloat16>), dim3((unsigned)blocks), dim3(TD_THREADS), 0, (hipStream_t)stream, acc, gscale,
+                       inv_count / (float)C, nvec, (__hip_bfloat16*)out);
+  else
+    hipLaunchKernelGGL((td::featwarp_dsrc_finish_kernel<float>), dim3((unsigned)blocks), dim3(TD_THREADS), 0, (hipStream_t)stream, acc, gscale,
+                       inv_count / (float)C, nvec, (float*)out);
+  return td::record_launch_error(hipGetLastError(), "td_featwarp_dsrc_finish");
 }

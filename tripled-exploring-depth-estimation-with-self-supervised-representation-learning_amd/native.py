@@ -89,6 +89,7 @@ SIGNATURES = {
     "td_featwarp_fwd": (_I, [_P, _PTRARR, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P]),
     "td_featwarp_bwd": (_I, [_P, _PTRARR, _I, _I, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _I, _F, _F, _P, _PTRARR,
                              _P, _P, _P]),
+    "td_featwarp_dsrc_finish": (_I, [_P, _P, _F, _I, ctypes.c_longlong, _I, _P, _P]),
     "td_reduce_partials": (_I, [_P, _I, _I, _I, _P, _P]),
     "td_bn_sync_fwd_sums": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _P, _P, _P]),
     "td_bn_sync_fwd_apply": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _P, _P, _P]),

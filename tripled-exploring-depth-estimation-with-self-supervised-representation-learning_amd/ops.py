@@ -1092,7 +1092,8 @@ class _FeatureWarpLoss(torch.autograd.Function):
         n_src = len(src_f)
         gs = _f32c(g.reshape(1))
         d_tgt = torch.empty_like(tgt_f, memory_format=torch.channels_last)
-        d_src32 = [torch.zeros((B, h, w, C), device=dev, dtype=torch.float32) for _ in src_f]
+        # int32 fixed-point accumulators of the scatter (integer atomics: order-independent, bit-reproducible)
+        d_src32 = [torch.zeros((B, h, w, C), device=dev, dtype=torch.int32) for _ in src_f]
         d_up = torch.empty(B, h, w, device=dev, dtype=torch.float32)
         dP_part = torch.empty(nblk, n_src * 12, device=dev, dtype=torch.float32)
         st = native.stream()
@@ -1107,8 +1108,14 @@ class _FeatureWarpLoss(torch.autograd.Function):
         dP = torch.empty_like(P)
         native.check(lib.td_reduce_partials(native.ptr(dP_part), n_src, B, nblk // B, native.ptr(dP), st),
                      "td_reduce_partials")
-        # NHWC f32 accumulators -> logical NCHW view in the feature dtype (still channels-last memory)
-        d_src = tuple(d.permute(0, 3, 1, 2).to(tgt_f.dtype) for d in d_src32)
+        # accumulators -> the gradient in the feature dtype, logical NCHW view of channels-last memory
+        d_src = []
+        for acc in d_src32:
+            out = torch.empty((B, h, w, C), device=dev, dtype=tgt_f.dtype)
+            native.check(lib.td_featwarp_dsrc_finish(native.ptr(acc), native.ptr(gs), inv_count, C, acc.numel(),
+                                                     native.DTYPE_CODES[tgt_f.dtype], native.ptr(out), st), "td_featwarp_dsrc_finish")
+            d_src.append(out.permute(0, 3, 1, 2))
+        d_src = tuple(d_src)
         return (d_tgt, d_disp, dP, None, None, None) + d_src
 
 
