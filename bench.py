@@ -437,6 +437,9 @@ def main():
             if dp:      # the warm-up's collectives have completed and the ranks line up before capturing;
                 dist.barrier()      # "thread_local": the process group's watchdog thread may query events meanwhile
                 torch.cuda.synchronize()
+                # ... and its work list is given time to drain (it polls every 100 ms): a hipEventQuery on a warm-up work's
+                # event from the watchdog thread while this thread is capturing aborted one one-rank RCCL rehearsal in round 4
+                time.sleep(0.5)
             # captured but NOT replayed yet: under N > 1 a replay executes collectives, so it must not start before every
             # rank is known to have captured successfully (main loop below)
             gs = capture_step(st, stream=cap, split=split, capture_error_mode="thread_local" if dp else "global", validate=False)

@@ -305,6 +305,9 @@ class RunnerIteration:
                 if dp:
                     dist.barrier()
                 torch.cuda.synchronize()
+                if dp:      # let the process group's watchdog (100 ms poll) retire the warm-up's works before the capture starts
+                    import time
+                    time.sleep(0.5)
                 g = capture_step(self.step, stream=stream, split=mode == "two-graph",
                                  capture_error_mode="thread_local" if dp else "global", validate=False)
             except Exception as e:      # noqa: BLE001 -- this form is not available here; the next one is tried
