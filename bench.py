@@ -54,7 +54,7 @@ def photo_bwd_bytes_per_px(s):
 
 PKG = os.path.join(ROOT, "tripled-exploring-depth-estimation-with-self-supervised-representation-learning_amd")
 # what a committed PMC figure depends on: it is only quoted in the line while these sources (and the workload) are the ones
-# it was measured on (tools/traffic_from_pmc.py and tools/mfma_summary.py write the same stamp into the file)
+# it was measured on (tools/traffic_from_pmc.py and tools/mfma_util.py write the same stamp into the file)
 TRAFFIC_SOURCES = ["csrc/td_photo_fwd.hip", "csrc/td_photo_bwd.hip", "csrc/td_common.h"]
 MFMA_SOURCES = ["csrc/td_conv1x1.hip", "csrc/td_bn.hip", "hostside/mono/model/networks.py", "ops.py"]
 

@@ -100,3 +100,29 @@ def test_runner_lr_schedule_checkpoint_resume(tmp_path):
     runner2.resume(str(tmp_path / "epoch_2.pth"), map_location="cpu")
     assert runner2.epoch == 2 and runner2.iter == 12
     assert any(f.endswith(".log.json") for f in os.listdir(tmp_path))
+
+
+def test_resume_keeps_the_execution_flags_of_the_live_optimizer(tmp_path):
+    """A reference / older checkpoint's param_groups carry no capturable / fused / foreach keys; torch's load_state_dict then
+    defaults them (capturable False, fused None), which on a GPU would refuse graph capture and put a host sync into every
+    eager step.  Runner.resume keeps the flags of the optimiser it was given (the flat store did so already)."""
+    model = Toy()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    runner = Runner(model, _bp, opt, str(tmp_path), "INFO")
+    runner.register_training_hooks(dict(policy="step", step=[1]), dict(grad_clip=None), dict(interval=1), dict(interval=50, hooks=[]))
+    runner.run([_loader()], [("train", 1)], 1)
+    ckpt = torch.load(tmp_path / "epoch_1.pth", weights_only=False)
+    for g in ckpt["optimizer"]["param_groups"]:            # what the reference's files look like
+        for k in ("capturable", "fused", "foreach", "differentiable"):
+            g.pop(k, None)
+    torch.save(ckpt, tmp_path / "old_format.pth")
+    model2 = Toy()
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-4, foreach=True)        # (capturable needs a device: GPU test)
+    runner2 = Runner(model2, _bp, opt2, str(tmp_path), "INFO")
+    runner2.resume(str(tmp_path / "old_format.pth"), map_location="cpu")
+    g = opt2.param_groups[0]
+    assert g["foreach"] is True
+    assert runner2.iter == 6 and abs(g["lr"] - ckpt["optimizer"]["param_groups"][0]["lr"]) < 1e-12
+    opt2.zero_grad()
+    model2.fc.weight.sum().backward()
+    opt2.step()                                           # state from the file + the live flags work together

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(64) void bn_coef_from_sums_kernel(const float* __re
 // each 64-channel block of bn_apply / bn_dx re-reduces the partials of ITS channels in its prologue instead: S x 64 float2,
 // all loads issued at once, the same ordered sum in every block, so all blocks of a launch normalise with bit-identical
 // statistics.  The blocks with blockIdx.y == 0 write save_mean / save_invstd (dgamma / dbeta), block (y, z) == (0, 0) updates
-// the running statistics group by group.  Larger S keeps the separate 16-channel finalize kernels above.
+// the running statistics group by group.  More than BN_PRO_MAX_S partial rows are first shrunk in place (bn_shrink_kernel above);
+// there is no finalize kernel any more.
 // ---------------------------------------------------------------------------------------------
 constexpr int BN_PRO_MAX_S = 96;
 constexpr int BN_PRO_PARTS = BN_THREADS / 64;

@@ -66,9 +66,10 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __res
 //   column inside that row; "NaN wins" = last NaN = last row holding one, last NaN inside it: the two-stage scan keeps both
 //   rules), then the same scan down the 5 ring rows.
 // Rows/columns outside the map load a clamped address and are replaced by -inf.
-// The backward stays the gather above: the same march needs a 5-way compare-select per (column, channel) element to find the
+// The backward is NOT this march turned around: that needs a 5-way compare-select per (column, channel) element to find the
 // input row an output's offset points at (136 us with a register ring, 167 us with a thread-private LDS ring and ds_add_f32
-// -- both more vector-ALU work than the gather's 124 us).
+// -- both more vector-ALU work than the gather's 124 us).  Maps of at least 1536 pixels with C % 64 == 0 take the LDS scatter
+// with column turns below (maxpool5_bwd_scatter_kernel, 66 us); smaller maps keep the 25-candidate gather above.
 struct MarchCoord {
   int cv, x, n, y0, y1;
   bool live;

@@ -158,12 +158,23 @@ class Runner:
             else:
                 # a device-side lr tensor (graph replay reads it) keeps its identity; the file's value is written into it
                 held = [g["lr"] if torch.is_tensor(g["lr"]) else None for g in self.optimizer.param_groups]
+                # the execution flags belong to THIS process, not to the file: a reference / older checkpoint carries no
+                # capturable / fused / foreach keys, and torch's __setstate__ would default them to False / None -- the graph
+                # capture would then be refused and the eager step would take the single-tensor path with a host sync per step
+                flags = [{k: g[k] for k in ("capturable", "fused", "foreach", "differentiable") if k in g}
+                         for g in self.optimizer.param_groups]
                 self.optimizer.load_state_dict(ckpt["optimizer"])
-                for group, t in zip(self.optimizer.param_groups, held):
+                for group, t, fl in zip(self.optimizer.param_groups, held, flags):
+                    group.update(fl)
                     if t is not None:
                         t.fill_(float(group["lr"]))
                         t._host_value = float(group["lr"])
                         group["lr"] = t
+                if any(fl.get("capturable") or fl.get("fused") for fl in flags):     # torch keeps the step count on the device then
+                    dev_of = {id(p): p.device for g in self.optimizer.param_groups for p in g["params"]}
+                    for p, st in self.optimizer.state.items():
+                        if "step" in st and torch.is_tensor(st["step"]) and st["step"].device != dev_of.get(id(p), st["step"].device):
+                            st["step"] = st["step"].to(dev_of[id(p)], torch.float32)
         self.logger.info("resumed epoch %d, iter %d", self.epoch, self.iter)
 
     def run(self, data_loaders, workflow, max_epochs, **kwargs):

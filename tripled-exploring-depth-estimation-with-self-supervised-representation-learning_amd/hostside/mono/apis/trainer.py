@@ -171,10 +171,21 @@ def _build_flat_store(model, cfg):
     return flat, FlatOptimizerHook(flat, **cfg.optimizer_config)
 
 
-def _use_hip_graph(cfg, dev):
+def _use_hip_graph(cfg, dev, model=None):
+    """Graph replay needs an iteration without host-side state: the reference's CPU-generator auto-mask noise
+    (automask_noise="cpu": drawn on the host and uploaded) or a recorded noise source (set_noise_source) would be
+    recorded ONCE and replayed for every iteration, so such a run takes the eager iteration (and says so)."""
     ocfg = cfg.optimizer
     default = dev.type == "cuda" and ocfg.get("type") == "Adam" and ocfg.get("paramwise_options") is None
-    return bool(cfg.get("hip_graph", default))
+    want = bool(cfg.get("hip_graph", default))
+    inner = getattr(model, "module", model)
+    host_rng = cfg.model.get("automask_noise", "device") == "cpu" or getattr(inner, "_noise_fn", None) is not None
+    if want and host_rng:
+        import logging
+        logging.getLogger(__name__).warning("hip_graph off: the model draws its auto-mask noise on the host (automask_noise='cpu' or a "
+                                            "noise source): a captured iteration would replay one draw for ever")
+        return False
+    return want
 
 
 def _graphed_iteration(model, cfg, dev, flat, logger=None):
@@ -230,7 +241,7 @@ def _dist_train(model, dataset_train, dataset_val, cfg, validate=False):
         from mono.model.networks import enable_sync_batchnorm
         enable_sync_batchnorm(model)
     model = configure_execution(model, cfg, dev)
-    use_flat, use_graph = _use_flat_store(cfg, dev), _use_hip_graph(cfg, dev)
+    use_flat, use_graph = _use_flat_store(cfg, dev), _use_hip_graph(cfg, dev, model)
     # under graph replay Python autograd hooks do not run: the bucket engine then exchanges after backward (overlap=False:
     # captured with the step on RCCL, eager between two graphs otherwise)
     model = MMDistributedDataParallel(model, find_unused_parameters=cfg.get("find_unused_parameters", False),
@@ -258,7 +269,7 @@ def _non_dist_train(model, dataset_train, dataset_val, cfg, validate=False):
     data_loaders = _loaders(dataset_train, cfg, dist=False)
     dev = _device()
     model = MMDataParallel(configure_execution(model, cfg, dev), device_ids=list(range(len(cfg.gpus))))
-    use_graph = _use_hip_graph(cfg, dev)
+    use_graph = _use_hip_graph(cfg, dev, model)
     flat, processor = None, batch_processor
     if _use_flat_store(cfg, dev):
         flat, opt_hook = _build_flat_store(model, cfg)

@@ -425,8 +425,11 @@ class _BatchNormAct(torch.autograd.Function):
 
 class _Conv1x1BatchNormAct(torch.autograd.Function):
     """relu?( batch_norm( conv1x1(x, w) ) [+ residual] ) with the convolution on the hand-written MFMA GEMM and the batch
-    statistics taken from its epilogue (no statistics pass over the convolution output): three launches -- GEMM, finalize,
-    apply.  Backward: td_bn_bwd, then the convolution's data / weight gradients through ATen (MIOpen)."""
+    statistics taken from its epilogue (no statistics pass over the convolution output): GEMM, [shrink of the partial rows when
+    there are more than 96], apply with the statistics finished in its prologue.  Backward: td_bn_bwd, the data gradient through
+    ATen (MIOpen), the weight gradient on the hand-written MFMA kernel (td_conv1x1_wgrad).  (The bottlenecks of the training
+    step take the block-level node _Bottleneck since round 4; this per-layer node serves the BasicBlock down-sample branch and
+    TD_NO_FUSED_BLOCK.)"""
 
     @staticmethod
     def forward(ctx, x, w, weight, bias, running_mean, running_var, residual, momentum, eps, relu, groups, stride):

@@ -319,7 +319,10 @@ class RunnerIteration:
                 # the graph's own output tensors: an eager iteration in between (a ragged batch) rebinds step.loss / step.losses
                 self._graph_out = (self.step.loss, self.step.losses)
                 break
-        self.logger.info("training iteration: %s%s", self.mode,
+        # every rank logs its own decision: a divergence between ranks (which ranks_agree is there to prevent) would be visible.
+        # The N > 1 forms (collectives captured in one graph on RCCL / two graphs around an eager all-reduce) have run on one
+        # GPU only (one-rank RCCL, two gloo ranks: tests/test_hip_runner_dp.py); no multi-GPU node was available to this build.
+        self.logger.info("[rank %d/%d] training iteration: %s%s", dist.get_rank() if self._world() > 1 else 0, self._world(), self.mode,
                          "" if self.graphed is None else " (captured on %s)" % ("one stream" if stream is not None
                                                                               else "the default capture stream"))
 
