@@ -91,7 +91,7 @@ def test_conv_bias_act_against_torch(B, H, W, Cin, Cout, act):
     d = (y.float() - yf).abs()
     assert bool((d <= 2.0 ** -6 * yf.abs() + 1e-2 * float(yf.abs().max())).all()), float(d.max())
     close(x.grad, dxf, "dx", 3e-2, 5e-3)       # sums of up to 2304 bf16-rounded products
-    close(w.grad, dwf, "dw", 3e-2, 1e-3)
+    close(w.grad, dwf, "dw", 3e-2, 5e-3)
     close(b.grad, dbf, "db", 2e-2)
 
 
