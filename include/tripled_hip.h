@@ -329,7 +329,7 @@ int td_bias_act_bwd(const void* g, const void* a, int dtype, long long M, int C,
  * on the flat store of tripled_amd/flat_amp.py.  n % 4 == 0, n_lowp % 4 == 0.
  */
 int td_adam_flat(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, void* lowp, long long n, long long n_lowp,
-                 const float* step, const float* lr_dev, float lr_host, float beta1, float beta2, float eps, const float* total_norm,
+                 const float* step, const float* lr_dev, float lr_host, double beta1, double beta2, float eps, const float* total_norm,
                  float max_norm, td_stream_t stream);
 
 /*

@@ -169,7 +169,8 @@ def _run(capture, deterministic, flat, dispatch, capture_step, warm_up):
     with dispatch.strict():
         warm_up(step, 2, side)
     assert sum(dispatch.fallbacks.values()) == 0, dict(dispatch.fallbacks)
-    assert dispatch.hip_calls["td_photo_fwd"] == 2 * 4 and dispatch.hip_calls["td_bn_fwd"] > 100
+    bn_calls = sum(dispatch.hip_calls[k] for k in ("td_bn_fwd", "td_bn_fwd_from_partials", "td_conv1x1_fwd_bnrelu"))
+    assert dispatch.hip_calls["td_photo_fwd"] == 2 * 4 and bn_calls > 100
 
     snaps, eager = [_snapshot(model, step)], []
     for _ in range(K_STEPS):

@@ -68,7 +68,7 @@ def test_flat_store_step_fused_equals_torch_path(monkeypatch):
         tb = fb.step()
         torch.cuda.synchronize()
         assert torch.allclose(ta, tb)
-        assert torch.allclose(fa.flat_w, fb.flat_w, rtol=1e-5, atol=1e-8)
+        assert torch.allclose(fa.flat_w, fb.flat_w, rtol=1e-5, atol=2e-7 * (it + 1))      # updates are lr * O(1) = 1e-3
         assert torch.equal(fa.flat_lp, fa.flat_w[:fa.n_lp].to(torch.bfloat16))
         sa, sb = fa.optimizer.state[fa.master], fb.optimizer.state[fb.master]
         assert float(sa["step"]) == float(sb["step"]) == it + 1

@@ -247,8 +247,13 @@ def test_runner_iteration_same_state_c2(wire):
                 rel_ge, rel_ee = float((ug - u1).norm()) / n1, float((u2 - u1).norm()) / n1
                 cos_ge = float(torch.dot(ug, u1)) / (float(ug.norm()) * n1 + 1e-30)
                 worst = min(worst, (cos_ge, name))
-                assert rel_ge <= 1.5 * rel_ee + 0.02, (wire, i, name, rel_ge, rel_ee)
-                assert cos_ge >= 0.9 or rel_ge <= rel_ee, (wire, i, name, cos_ge, rel_ge, rel_ee)
+                # measured (round 4, tools of DESIGN.md section 6): two EAGER iterations from one state differ by 50-80 % in the
+                # ResNet50 encoders' gradients at this early iteration whenever MIOpen runs its order-dependent solvers (the
+                # per-pixel arg-min and ReLU masks turn 1e-3 of forward noise into different selections) -- the round-3 tree
+                # gives the same spread -- and by 1e-3 when it runs deterministic ones (a fresh process right after a capture).
+                # The bound follows the measured eager-vs-eager spread; a wrong replay (~1.41, cosine ~0) fails either way.
+                assert rel_ge <= 1.25 * rel_ee + 0.02, (wire, i, name, rel_ge, rel_ee)
+                assert cos_ge >= 0.9 or rel_ge <= 0.95, (wire, i, name, cos_ge, rel_ge, rel_ee)
             d = (w_e1 - got[1]).abs()
             print("[runner %s same-state %d] parameters: max %.2f lr, mean %.4f lr; worst sub-network cosine %.4f (%s)"
                   % (wire, i, float(d.max()) / lr, float(d.mean()) / lr, worst[0], worst[1]))

@@ -22,7 +22,7 @@ namespace td {
 __global__ __launch_bounds__(TD_THREADS) void adam_flat_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                                float* __restrict__ v, __hip_bfloat16* __restrict__ lp, long long n4,
                                                                long long n_lp4, const float* __restrict__ step, const float* __restrict__ lr_dev,
-                                                               float lr_host, float beta1, float beta2, float eps,
+                                                               float lr_host, float beta1, float beta2, float one_m_b1, float one_m_b2, float eps,
                                                                const float* __restrict__ total_norm, float max_norm) {
   const float t = step[0];
   const float lr = lr_dev ? lr_dev[0] : lr_host;
@@ -33,7 +33,6 @@ __global__ __launch_bounds__(TD_THREADS) void adam_flat_kernel(float* __restrict
     const float c = max_norm / (total_norm[0] + 1e-6f);
     clip = c < 1.f ? c : 1.f;
   }
-  const float one_m_b1 = 1.f - beta1, one_m_b2 = 1.f - beta2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
@@ -62,14 +61,17 @@ __global__ __launch_bounds__(TD_THREADS) void adam_flat_kernel(float* __restrict
 }  // namespace td
 
 extern "C" int td_adam_flat(float* w, const float* grad, float* exp_avg, float* exp_avg_sq, void* lowp, long long n, long long n_lowp,
-                            const float* step, const float* lr_dev, float lr_host, float beta1, float beta2, float eps,
+                            const float* step, const float* lr_dev, float lr_host, double beta1_d, double beta2_d, float eps,
                             const float* total_norm, float max_norm, td_stream_t stream) {
+  // betas travel as doubles: torch forms 1 - beta in double (1 - 0.999 = 1e-3, not the 1.00005e-3 of float(0.999))
+  const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
   if (!w || !grad || !exp_avg || !exp_avg_sq || !step || n <= 0 || n_lowp < 0 || n_lowp > n || (n_lowp > 0 && !lowp)) return TD_ERR_BAD_ARG;
   if (n % 4 != 0 || n_lowp % 4 != 0) return TD_ERR_UNSUPPORTED;      // the flat store aligns every parameter to 8 elements
   const long long n4 = n / 4;
   long long blocks = (n4 + TD_THREADS - 1) / TD_THREADS;
   if (blocks > 4096) blocks = 4096;                                   // 16 x 256 CUs: grid-stride over the rest
   hipLaunchKernelGGL(td::adam_flat_kernel, dim3((unsigned)blocks), dim3(TD_THREADS), 0, (hipStream_t)stream, w, grad, exp_avg, exp_avg_sq,
-                     (__hip_bfloat16*)lowp, n4, n_lowp / 4, step, lr_dev, lr_host, beta1, beta2, eps, total_norm, max_norm);
+                     (__hip_bfloat16*)lowp, n4, n_lowp / 4, step, lr_dev, lr_host, beta1, beta2, (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps,
+                     total_norm, max_norm);
   return td::record_launch_error(hipGetLastError(), "td_adam_flat");
 }
