@@ -201,6 +201,10 @@ int td_maxpool5_fwd(const void* in, int dtype, int N, int H, int W, int C, void*
                     td_stream_t stream);
 int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dtype, int N, int H, int W, int C,
                     void* grad_in, td_stream_t stream);
+/* The same with a tensor add [N,H,W,C] (nullable) summed into the result: grad_in = maxpool5_backward(grad_out) + add -- the gradient an
+ * input of the CRP block's chain receives both through its pool and directly from the running sum (layers.py:200-215). */
+int td_maxpool5_bwd_add(const void* grad_out, const uint8_t* idx, const void* add, int dtype, int N, int H, int W, int C,
+                        void* grad_in, td_stream_t stream);
 
 /*
  * The ResNet stem pool, nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (mono/model/mono_fm_joint/resnet.py:101),
@@ -373,6 +377,10 @@ int td_conv1x1_fwd_bnrelu(const void* z, const void* w, long long M, int groups,
                           float* save_mean, float* save_invstd, void* a_side, void* y, float* stat_partials, td_stream_t stream);
 int td_conv1x1_dgrad(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* residual, void* dx,
                      td_stream_t stream);
+/* y = conv1x1(x, w) [M, N] and run_out = run_in + y (both bf16 [M, N]; run_out rounded from the bf16 y + run_in, as the tensor add
+ * would be): the pointwise convolution of a CRP stage with the block's running sum in its epilogue (layers.py:200-215). */
+int td_conv1x1_fwd_sum(const void* x, const void* w, long long M, int K, int N, const void* run_in, void* y, void* run_out,
+                       td_stream_t stream);
 int td_conv1x1_dgrad_bnsums(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* z,
                             const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, void* dx,
                             float* out_partials, td_stream_t stream);

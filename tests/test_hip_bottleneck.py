@@ -343,3 +343,64 @@ def test_fused_block_against_per_layer_path_and_fp32(B, H, W, inplanes, planes, 
         assert e <= rel, (what, e)
     for k in g_u:
         l2(g_f[k], p[k].grad, k + " vs fp32", 0.12)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(12, 6, 20, 256), (4, 24, 80, 256), (2, 48, 160, 256), (3, 7, 11, 64)])
+def test_fused_crp_block_against_per_op_path_and_fp32(B, H, W, C):
+    """networks.CRPBlock under bf16 autocast: the fused node (tripled_amd.ops.crp_block: pools + GEMMs with the running sum in
+    the epilogue + pool backward with the direct gradient added) against the per-op path (MIOpen 1x1 convolutions + tensor adds:
+    same rounding points up to the order of the two roundings of a sum; output within 2^-6 |y| + 0.02, gradients within 2 % of
+    their maxima up to 1e-3 of the elements: max-pool selections flip where two bf16 values tie differently) and against the
+    fp32 composite (reference: layers.py:200-215)."""
+    import tripled_amd  # noqa: F401
+    from mono.model import networks
+    from tripled_amd import dispatch
+    torch.manual_seed(5)
+    blk = networks.CRPBlock(C, C, 4).cuda().to(memory_format=torch.channels_last).train()
+    x0 = torch.randn(B, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    up = torch.randn(B, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(fused):
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        prev = networks.FUSED_CRP_OFF
+        networks.FUSED_CRP_OFF = not fused
+        try:
+            dispatch.reset()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(x)
+            (y.float() * up.float()).sum().backward()
+            calls = dict(dispatch.hip_calls)
+        finally:
+            networks.FUSED_CRP_OFF = prev
+        torch.cuda.synchronize()
+        return y.detach().float(), x.grad.float(), {k: p.grad.float().clone() for k, p in blk.named_parameters()}, calls
+
+    y_f, dx_f, g_f, calls_f = run(True)
+    y_u, dx_u, g_u, calls_u = run(False)
+    assert calls_f.get("td_conv1x1_fwd_sum") == 4 and calls_f.get("td_maxpool5_bwd_add") == 4 and calls_f.get("td_conv1x1_dgrad") == 4
+    assert "td_conv1x1_fwd_sum" not in calls_u
+
+    def close(a, b, what, rel, outliers):
+        err = (a - b).abs() / max(float(b.abs().max()), 1e-12)
+        bad = float((err >= rel).float().mean())
+        assert bad <= outliers, (what, float(err.max()), bad)
+    d = (y_f - y_u).abs()
+    assert bool((d <= 2.0 ** -6 * y_u.abs() + 0.02).all()), float(d.max())
+    close(dx_f, dx_u, "dx", 2e-2, 2e-3)
+    for k in g_u:
+        close(g_f[k], g_u[k], k, 2e-2, 2e-3)
+    # fp32 composite on the bf16-rounded weights
+    ws = [p.detach().to(torch.bfloat16).float().requires_grad_(True) for _, p in blk.named_parameters()]
+    xr = x0.float().clone().requires_grad_(True)
+    top, out = xr, xr
+    for w in ws:
+        top = F.conv2d(F.max_pool2d(top, 5, 1, 2), w)
+        out = out + top
+    (out * up.float()).sum().backward()
+    d = (y_f - out.detach()).abs()
+    assert bool((d <= 0.05 + 2.0 ** -5 * out.detach().abs()).all()), float(d.max())
+    l2 = lambda a, b: float((a - b).norm()) / max(float(b.norm()), 1e-30)
+    assert l2(dx_f, xr.grad) <= 0.08, l2(dx_f, xr.grad)
+    for (k, _), w in zip(blk.named_parameters(), ws):
+        assert l2(g_f[k], w.grad) <= 0.08, (k, l2(g_f[k], w.grad))

@@ -132,3 +132,26 @@ def test_maxpool5_scatter_backward_adversarial(dtype, N, C, H, W, kind, mass):
     assert torch.equal(y, yr)
     assert torch.equal(xd.grad, xr.grad), float((xd.grad.float() - xr.grad.float()).abs().max())
     assert float(xd.grad.float().sum()) == float(upd.float().sum())      # no gradient lost or duplicated
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 7, 9), (2, 64, 24, 80), (1, 128, 37, 53)])      # gather / scatter backward
+def test_maxpool5_backward_with_added_gradient(dtype, N, C, H, W):
+    """td_maxpool5_bwd_add == td_maxpool5_bwd + add (the CRP block's direct gradient), integer-valued data: exact."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native
+    from tripled_amd.ops import _raw
+    lib = native.load()
+    g = torch.Generator().manual_seed(1)
+    cl = lambda t: t.to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    x = cl(torch.randint(0, 6, (N, C, H, W), generator=g).float())
+    go = cl(torch.randint(0, 3, (N, C, H, W), generator=g).float())
+    add = cl(torch.randint(-3, 4, (N, C, H, W), generator=g).float())
+    out, idx = torch.empty_like(x), torch.empty((N, H, W, C), device="cuda", dtype=torch.uint8)
+    code = native.DTYPE_CODES[dtype]
+    native.check(lib.td_maxpool5_fwd(_raw(x), code, N, H, W, C, _raw(out), _raw(idx), native.stream()), "fwd")
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    native.check(lib.td_maxpool5_bwd(_raw(go), _raw(idx), code, N, H, W, C, _raw(a), native.stream()), "bwd")
+    native.check(lib.td_maxpool5_bwd_add(_raw(go), _raw(idx), _raw(add), code, N, H, W, C, _raw(b), native.stream()), "bwd_add")
+    torch.cuda.synchronize()
+    assert torch.equal(b.float(), a.float() + add.float())

@@ -590,6 +590,17 @@ extern "C" int td_conv1x1_fwd_bnrelu(const void* z, const void* w, long long M, 
   return td::cv_dispatch<false, 1, 0>(z, w, y, stat_partials, M, groups, K, N, td::ConvRows{0, 0, 0, 0, 1}, st, fz);
 }
 
+// y = conv1x1(x, w) and run_out = run_in + y in one launch (the CRP block's pointwise convolution + running sum)
+extern "C" int td_conv1x1_fwd_sum(const void* x, const void* w, long long M, int K, int N, const void* run_in, void* y, void* run_out,
+                                  td_stream_t stream) {
+  if (!x || !w || !y || !run_in || !run_out || !cv_shape_ok(M, 1, K, N)) return TD_ERR_BAD_ARG;
+  if (M * (long long)(K > N ? K : N) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+  td::CvFuse fz = {};
+  fz.ep.res = (const __hip_bfloat16*)run_in;
+  fz.ep.y2 = (__hip_bfloat16*)run_out;
+  return td::cv_dispatch<false, 0, 3>(x, w, y, nullptr, M, 1, K, N, td::ConvRows{0, 0, 0, 0, 1}, (hipStream_t)stream, fz);
+}
+
 // Data gradient dX[M, Cin] = dY[M, Cout] . W[Cout, Cin] (stride 1).
 extern "C" int td_conv1x1_dgrad(const void* dy, const void* w, long long M, int groups, int Cout, int Cin, const void* residual,
                                 void* dx, td_stream_t stream) {

@@ -95,8 +95,11 @@ __device__ __forceinline__ void cv_stage_mfma(CvAcc<BM, BN>& acc, const unsigned
 //   2  the BACKWARD sums of the BatchNorm whose output this tensor is the gradient of (data gradient of the convolution that
 //      consumed relu(bn(z))): ws <- (sum g, sum g (z - mean)) with g = y * [fma(z, gamma invstd, beta - mean gamma invstd) > 0],
 //      i.e. td_bn_bwd's statistics pass (relu mask recomputed from z) without reading the gradient back
+//   3  two outputs: y as computed and y2 = y + res (rounded again): a convolution whose result also joins a running sum
+//      (the CRP block's top_i = conv(pool(top_{i-1})), x_i = x_{i-1} + top_i, mono/model/mono_fm_joint/layers.py:200-215)
 struct CvEpi {
-  const __hip_bfloat16* res;      // EPI 1: [M, N]
+  __hip_bfloat16* y2;             // EPI 3: [M, N] second output
+  const __hip_bfloat16* res;      // EPI 1 / 3: [M, N]
   const __hip_bfloat16* z;        // EPI 2: [M, N] input of the BatchNorm
   const float* gamma;             // EPI 2: [N]
   const float* beta;              // EPI 2: [N]
@@ -148,7 +151,8 @@ __device__ __forceinline__ void cv_epilogue(CvAcc<BM, BN>& acc, unsigned char* l
     if (r < rows_valid) {
       unsigned wv[4] = {lo.x, lo.y, hi.x, hi.y};
       const long long off = (row0 + r) * (long long)N + n0 + cx * 8;
-      if constexpr (EPI == 1) {
+      if constexpr (EPI == 3) *reinterpret_cast<uint4*>(y + off) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      if constexpr (EPI == 1 || EPI == 3) {
         const uint4 rr = *reinterpret_cast<const uint4*>(ep.res + off);
         const unsigned rv[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
@@ -158,7 +162,7 @@ __device__ __forceinline__ void cv_epilogue(CvAcc<BM, BN>& acc, unsigned char* l
           wv[e] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
         }
       }
-      *reinterpret_cast<uint4*>(y + off) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      *reinterpret_cast<uint4*>((EPI == 3 ? ep.y2 : y) + off) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
       if constexpr (EPI == 0) {
         if (stats) {
 #pragma unroll

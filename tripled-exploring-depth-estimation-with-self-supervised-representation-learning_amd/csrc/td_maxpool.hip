@@ -16,7 +16,7 @@ namespace td {
 template <typename T>
 __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __restrict__ gout,
                                                                   const uint8_t* __restrict__ idx, int N, int H,
-                                                                  int W, int C, T* __restrict__ gin) {
+                                                                  int W, int C, T* __restrict__ gin, const T* __restrict__ add) {
   const int c8 = C >> 3;
   const long long gid = (long long)blockIdx.x * TD_THREADS + threadIdx.x;
   const long long total = (long long)N * H * W * c8;
@@ -51,6 +51,12 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_kernel(const T* __res
         if (((w1 >> (8 * i)) & 0xff) == want) acc[4 + i] += g[4 + i];
       }
     }
+  }
+  if (add) {                                  // + a gradient the input also receives directly (the CRP block's running sum)
+    float r[8];
+    load8(add + (size_t)pix * C + (size_t)cv * 8, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += r[i];
   }
   store8(gin + (size_t)pix * C + (size_t)cv * 8, acc);
 }
@@ -204,7 +210,8 @@ constexpr int MS_COLS = 32, MS_OWN = MS_COLS - 4, MS_SLOTS = 6;
 constexpr int MS_PLANE = MS_SLOTS * MS_COLS * 8;             // floats per channel-in-vector array: [slot][column][vector]
 template <typename T>
 __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_scatter_kernel(const T* __restrict__ gout, const uint8_t* __restrict__ idx, int N,
-                                                                          int H, int W, int C, int TH, T* __restrict__ gin) {
+                                                                          int H, int W, int C, int TH, T* __restrict__ gin,
+                                                                          const T* __restrict__ add) {
   __shared__ float t0[MS_PLANE], t1[MS_PLANE], t2[MS_PLANE], t3[MS_PLANE], t4[MS_PLANE], t5[MS_PLANE], t6[MS_PLANE], t7[MS_PLANE];
   float* const plane[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
   const int tid = threadIdx.x, cv = tid & 7, lc = tid >> 3;   // channel vectors fastest: a wave reads 8 whole 128-byte pixel slabs
@@ -278,7 +285,16 @@ __global__ __launch_bounds__(TD_THREADS) void maxpool5_bwd_scatter_kernel(const 
         a[i] = plane[i][b * (MS_COLS * 8) + me];
         plane[i][b * (MS_COLS * 8) + me] = 0.f;
       }
-      if (own && y >= y0 && y < y1) store8(gin + nb + ((size_t)y * W + ox) * C, a);
+      if (own && y >= y0 && y < y1) {
+        const size_t o = nb + ((size_t)y * W + ox) * C;
+        if (add) {
+          float r8[8];
+          load8(add + o, r8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) a[i] += r8[i];
+        }
+        store8(gin + o, a);
+      }
       b = b + 1 == MS_SLOTS ? 0 : b + 1;
     }
   }
@@ -379,7 +395,8 @@ static int run_maxpool3s2(bool fwd, const void* a, const void* aux, int N, int H
 }
 
 template <typename T>
-static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, int W, int C, void* o, void* o2, hipStream_t st) {
+static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, int W, int C, void* o, void* o2, hipStream_t st,
+                       const void* add = nullptr) {
   if (fwd) {
     // strips of TH rows: enough threads to fill the chip on the small maps, at most (TH + 4) / TH re-read on the large ones
     int TH = H / 6;
@@ -400,12 +417,12 @@ static int run_maxpool(bool fwd, const void* a, const void* aux, int N, int H, i
     int TH = (int)((H + strips - 1) / strips);
     TH = TH < 8 ? 8 : TH;
     const dim3 grid((W + MS_OWN - 1) / MS_OWN, (H + TH - 1) / TH, N * (C / 64));
-    hipLaunchKernelGGL((maxpool5_bwd_scatter_kernel<T>), grid, dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, TH, (T*)o);
+    hipLaunchKernelGGL((maxpool5_bwd_scatter_kernel<T>), grid, dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, TH, (T*)o, (const T*)add);
     return record_launch_error(hipGetLastError(), "td_maxpool5_bwd");
   }
   const long long total = (long long)N * H * W * (C / 8);
   const unsigned blocks = (unsigned)((total + TD_THREADS - 1) / TD_THREADS);
-  hipLaunchKernelGGL((maxpool5_bwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, (T*)o);
+  hipLaunchKernelGGL((maxpool5_bwd_kernel<T>), dim3(blocks), dim3(TD_THREADS), 0, st, (const T*)a, (const uint8_t*)aux, N, H, W, C, (T*)o, (const T*)add);
   return record_launch_error(hipGetLastError(), "td_maxpool5_bwd");
 }
 
@@ -426,6 +443,15 @@ extern "C" int td_maxpool5_bwd(const void* grad_out, const uint8_t* idx, int dty
   if (C % 8 != 0) return TD_ERR_UNSUPPORTED;
   if (dtype == TD_DTYPE_BF16) return td::run_maxpool<__hip_bfloat16>(false, grad_out, idx, N, H, W, C, grad_in, nullptr, (hipStream_t)stream);
   if (dtype == TD_DTYPE_F32) return td::run_maxpool<float>(false, grad_out, idx, N, H, W, C, grad_in, nullptr, (hipStream_t)stream);
+  return TD_ERR_UNSUPPORTED;
+}
+
+extern "C" int td_maxpool5_bwd_add(const void* grad_out, const uint8_t* idx, const void* add, int dtype, int N, int H, int W, int C,
+                                   void* grad_in, td_stream_t stream) {
+  if (!grad_out || !idx || !grad_in || N <= 0 || H <= 0 || W <= 0 || C <= 0) return TD_ERR_BAD_ARG;
+  if (C % 8 != 0) return TD_ERR_UNSUPPORTED;
+  if (dtype == TD_DTYPE_BF16) return td::run_maxpool<__hip_bfloat16>(false, grad_out, idx, N, H, W, C, grad_in, nullptr, (hipStream_t)stream, add);
+  if (dtype == TD_DTYPE_F32) return td::run_maxpool<float>(false, grad_out, idx, N, H, W, C, grad_in, nullptr, (hipStream_t)stream, add);
   return TD_ERR_UNSUPPORTED;
 }
 

@@ -641,6 +641,7 @@ class _KeepChannels(torch.autograd.Function):
 
 
 FUSED_BIAS_ACT_OFF = bool(os.environ.get("TD_NO_FUSED_BIAS_ACT"))
+FUSED_CRP_OFF = bool(os.environ.get("TD_NO_FUSED_CRP"))        # CRP blocks as per-op autograd nodes (round 3's path)
 
 
 def _activate(y, act):
@@ -788,7 +789,25 @@ class CRPBlock(nn.Module):
         _fell_back("CRPBlock.maxpool", t)
         return self.maxpool(t)
 
+    def _fused(self, x):
+        """The whole block as one autograd node over the hand-written pool / GEMM kernels (tripled_amd.ops.crp_block), or None."""
+        if FUSED_CRP_OFF or _FP8_1X1[0] or not (self.training and x.is_cuda and torch.is_grad_enabled()):
+            return None
+        if not (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return None
+        convs = [getattr(self, "{}_{}".format(i + 1, "pointwise")).conv for i in range(self.n_stages)]
+        if any(c.bias is not None for c in convs):
+            return None
+        xb = _dense_cl(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
+        ws = [c.weight if c.weight.dtype == torch.bfloat16 else c.weight.to(torch.bfloat16) for c in convs]
+        if not _ops().crp_supported(xb, ws):
+            return None
+        return _ops().crp_block(xb, ws)
+
     def forward(self, x):
+        y = self._fused(x)
+        if y is not None:
+            return y
         top = x
         for i in range(self.n_stages):
             top = getattr(self, "{}_{}".format(i + 1, "pointwise"))(self._pool(top))

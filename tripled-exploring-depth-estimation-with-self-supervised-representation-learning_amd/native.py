@@ -45,6 +45,8 @@ SIGNATURES = {
     "td_smooth_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _P]),
     "td_maxpool5_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_maxpool5_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "td_maxpool5_bwd_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "td_conv1x1_fwd_sum": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _P, _P, _P, _P]),
     "td_maxpool3s2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_maxpool3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "td_join_fwd": (_I, [_P, _P, _P, _I, ctypes.c_longlong, _I, _I, _I, _P, _P]),

@@ -294,6 +294,88 @@ def maxpool5(x):
     return _MaxPool5.apply(x)
 
 
+class _CRP(torch.autograd.Function):
+    """Chained residual pooling (reference: CRPBlock, mono/model/mono_fm_joint/layers.py:200-215): top_0 = x,
+    top_i = conv1x1_i(maxpool5(top_{i-1})), out = x + sum_i top_i -- as ONE autograd node over hand-written kernels:
+
+      forward   per stage: the 5x5 pool (column march) and the pointwise convolution on the MFMA GEMM whose epilogue also
+                advances the running sum (td_conv1x1_fwd_sum: two outputs, no separate add pass)
+      backward  per stage, last to first: weight gradient (td_conv1x1_wgrad), data gradient (td_conv1x1_dgrad) and the pool's
+                backward with the gradient the stage's input ALSO receives straight from the running sum added while it is
+                written out (td_maxpool5_bwd_add): autograd's gradient-accumulation adds are gone
+
+    Against the per-op nodes: 8 tensor adds per block and direction fewer, and the twelve 1x1 convolution calls of a block
+    (forward / data / weight gradient through MIOpen / CK, the weight gradients with their zero-fill and cast passes) run on the
+    deterministic hand-written GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        lib = native.load()
+        strm = native.stream()
+        Nb, C, H, W = x.shape
+        M = Nb * H * W
+        BF = native.DTYPE_CODES[x.dtype]
+        top, run = x, x
+        saved = []
+        for w in ws:
+            pooled = torch.empty_like(x, memory_format=torch.channels_last)
+            idx = torch.empty((Nb, H, W, C), device=x.device, dtype=torch.uint8)
+            native.check(lib.td_maxpool5_fwd(_raw(top), BF, Nb, H, W, C, _raw(pooled), _raw(idx), strm), "td_maxpool5_fwd")
+            top = torch.empty_like(x, memory_format=torch.channels_last)
+            run_out = torch.empty_like(x, memory_format=torch.channels_last)
+            native.check(lib.td_conv1x1_fwd_sum(_raw(pooled), _raw(w), M, C, C, _raw(run), _raw(top), _raw(run_out), strm),
+                         "td_conv1x1_fwd_sum")
+            run = run_out
+            saved += [pooled, idx]
+        ctx.save_for_backward(*ws, *saved)
+        ctx.n = len(ws)
+        return run
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = native.load()
+        strm = native.stream()
+        n = ctx.n
+        ws, saved = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        Nb, C, H, W = g.shape
+        M = Nb * H * W
+        if g.dtype != torch.bfloat16 or not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        BF = native.DTYPE_CODES[g.dtype]
+        g_top = g
+        dws = [None] * n
+        for i in reversed(range(n)):
+            w, pooled, idx = ws[i], saved[2 * i], saved[2 * i + 1]
+            dw = torch.empty_like(w)
+            wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, C, C), device=g.device, dtype=torch.float32)
+            native.check(lib.td_conv1x1_wgrad(_raw(g_top), _raw(pooled), M, C, C, H, W, 1, native.DTYPE_CODES[w.dtype], _raw(dw),
+                                              native.ptr(wsw), strm), "td_conv1x1_wgrad")
+            dws[i] = dw
+            d_pool = torch.empty_like(g, memory_format=torch.channels_last)
+            native.check(lib.td_conv1x1_dgrad(_raw(g_top), _raw(w), M, 1, C, C, None, _raw(d_pool), strm), "td_conv1x1_dgrad")
+            g_prev = torch.empty_like(g, memory_format=torch.channels_last)
+            native.check(lib.td_maxpool5_bwd_add(_raw(d_pool), _raw(idx), _raw(g), BF, Nb, H, W, C, _raw(g_prev), strm),
+                         "td_maxpool5_bwd_add")
+            g_top = g_prev
+        return (g_top,) + tuple(dws)
+
+
+def crp_supported(x, ws):
+    C = x.shape[1]
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+            and C % 64 == 0 and len(ws) >= 1
+            and all(w.dtype == torch.bfloat16 and tuple(w.shape) == (C, C, 1, 1)
+                    and (w.is_contiguous() or w.is_contiguous(memory_format=torch.channels_last)) for w in ws))
+
+
+def crp_block(x, ws):
+    """x + sum_i top_i, top_i = conv1x1(maxpool5(top_{i-1}), ws[i]) (reference: layers.py:200-215) on bf16 channels_last HIP
+    tensors with C % 64 == 0 (one autograd node, see _CRP)."""
+    if not crp_supported(x, ws):
+        raise native.NativeLibraryError("crp_block needs a bf16 channels_last HIP tensor with C % 64 == 0 and [C, C, 1, 1] weights")
+    return _CRP.apply(x, *ws)
+
+
 class _JoinChannels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, tail):
