@@ -337,6 +337,15 @@ int td_adam_flat(float* w, const float* grad, float* exp_avg, float* exp_avg_sq,
                  float max_norm, td_stream_t stream);
 
 /*
+ * flat[dst_offsets[i] + e] = (float) srcs[i][e] for e < numels[i], i < n; srcs[i] == NULL zero-fills the slot.  srcs / dst_offsets /
+ * numels are HOST arrays (the pointers travel in the kernel arguments, 64 tensors per launch: legal under graph capture); all
+ * sources have the dtype src_dtype (bf16 or f32).  The gradient gather of the flat parameter store (tripled_amd/flat_amp.py):
+ * replaces torch.cat over the per-parameter gradients + the bf16 -> f32 pass.
+ */
+int td_gather_flat(const void* const* srcs, const long long* dst_offsets, const long long* numels, int n, int src_dtype, float* flat,
+                   td_stream_t stream);
+
+/*
  * Fused forms of the bottleneck's 1x1 convolutions (round 4): the BatchNorm passes of the NEIGHBOURING layers ride on the GEMM's
  * operand staging and epilogue instead of being separate passes over the activations.  Reference: Bottleneck.forward,
  * mono/model/mono_fm_joint/resnet.py:66-86 (conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3 -> += identity -> relu)

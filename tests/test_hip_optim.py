@@ -74,3 +74,34 @@ def test_flat_store_step_fused_equals_torch_path(monkeypatch):
         assert float(sa["step"]) == float(sb["step"]) == it + 1
         assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-9)
         assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
+def test_gradient_gather_equals_the_concatenation_path(monkeypatch):
+    """FlatMixedPrecision.collect(): td_gather_flat (pointers in the kernel arguments, bf16 -> fp32 on the way) against the torch.cat
+    + cast path, bit for bit -- including a parameter no gradient reached (its slot must read zero), odd sizes and more than 64
+    tensors (two launches per group)."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd.flat_amp import FlatMixedPrecision
+    torch.manual_seed(2)
+    layers = []
+    for i in range(40):
+        layers += [torch.nn.Conv2d(8 + (i % 3), 8 + ((i + 1) % 3), 3 if i % 2 else 1), torch.nn.BatchNorm2d(8 + ((i + 1) % 3))]
+    net = torch.nn.Sequential(*layers).cuda().to(memory_format=torch.channels_last)
+    flat = FlatMixedPrecision(net, lr=1e-3, max_norm=None, lowp=True)
+    assert len(flat.lowp) > 64 and len(flat.full) > 64
+    for i, p in enumerate(flat.params):
+        p.grad = None if i % 17 == 5 else torch.randn_like(p)
+    flat.flat_g.fill_(123.0)                       # stale contents must not survive in the parameter slots
+    with torch.no_grad():                          # ... and the pads are zero in both paths
+        for p, off in zip(flat.params, flat.offsets):
+            pass
+    monkeypatch.setenv("TD_NO_NATIVE_GATHER", "1")
+    flat.flat_g.zero_()
+    flat.collect()
+    ref = flat.flat_g.clone()
+    monkeypatch.delenv("TD_NO_NATIVE_GATHER")
+    flat.flat_g.zero_()
+    flat.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(flat.flat_g, ref)
+    assert float(ref.abs().sum()) > 0

@@ -242,10 +242,39 @@ class FlatMixedPrecision:
         out.copy_(g)
         return out
 
+    def _gather_native(self, params, offsets, dtype):
+        """One hand-written gather (td_gather_flat) for the gradients of ``params``: pointers in the kernel arguments, the
+        bf16 -> fp32 conversion on the way, pads untouched (they are zero from construction)."""
+        import ctypes
+        from . import native
+        n = len(params)
+        srcs = (ctypes.c_void_p * n)()
+        dst = (ctypes.c_longlong * n)(*offsets)
+        num = (ctypes.c_longlong * n)(*[p.numel() for p in params])
+        keep = []
+        for i, p in enumerate(params):
+            g = p.grad
+            if g is None:
+                srcs[i] = None
+                continue
+            if g.stride() != p.stride() or g.dtype != dtype:
+                g = self._relayout(g, p, dtype)
+            keep.append(g)
+            srcs[i] = g.data_ptr()
+        native.check(native.load().td_gather_flat(srcs, dst, num, n, native.DTYPE_CODES[dtype], native.ptr(self.flat_g),
+                                                  native.stream()), "td_gather_flat")
+
     def collect(self):
         """Per-parameter gradients (fresh autograd allocations, bf16 for convolutions / fp32 otherwise) -> the
-        flat fp32 gradient buffer: batched concatenations (128 tensors per launch) plus ONE bf16->fp32 cast."""
+        flat fp32 gradient buffer.  HIP device: two hand-written gathers (bf16 group with the conversion fused, fp32 group);
+        elsewhere batched concatenations (128 tensors per launch) plus ONE bf16->fp32 cast."""
         k = len(self.lowp)
+        if self.flat_g.is_cuda and not os.environ.get("TD_NO_NATIVE_GATHER") and (not k or self.flat_lp.dtype == torch.bfloat16):
+            if k:
+                self._gather_native(self.lowp, self.offsets[:k], self.flat_lp.dtype)
+            if self.full:
+                self._gather_native(self.full, self.offsets[k:], torch.float32)
+            return
         if k:
             torch.cat(self._flat_sources(self.lowp, self.offsets[:k], self.n_lp, self.flat_lp.dtype), out=self.flat_glp)
             self.flat_g[:self.n_lp].copy_(self.flat_glp)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "td_bias_act_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I]),
     "td_bias_act_fwd": (_I, [_P, _P, _I, _I, ctypes.c_longlong, _I, _I, _P, _P]),
     "td_bias_act_bwd": (_I, [_P, _P, _I, ctypes.c_longlong, _I, _I, _P, _P, _I, _P, _P]),
+    "td_gather_flat": (_I, [_PTRARR, _LLARR, _LLARR, _I, _I, _P, _P]),
     "td_adam_flat": (_I, [_P, _P, _P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P, _F, ctypes.c_double, ctypes.c_double, _F, _P, _F, _P]),
     "td_bn_partial_rows": (_I, [ctypes.c_longlong, _I, _I]),
     "td_bn_fwd_partials": (_I, [_P, _I, ctypes.c_longlong, _I, _I, _P, _P]),
