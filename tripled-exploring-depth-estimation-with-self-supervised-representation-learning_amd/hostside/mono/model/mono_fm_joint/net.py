@@ -354,7 +354,7 @@ class mono_fm_joint(nn.Module):
         n_scales = len(opt.scales)
         for i in range(5):
             loss_dict[("feature_regularization_loss", i)] = \
-                self.get_feature_regularization_loss(features[i], target) / (2 ** i) / 5
+                self.get_feature_regularization_loss(features[i], target) * (1.0 / ((2 ** i) * 5))     # (/ 2^i / 5: exact powers of two times 0.2, one launch)
         ctx = self._begin_step(inputs)
         for scale in opt.scales:
             res_img = outputs[("res_img", 0, scale)].float()

@@ -89,7 +89,7 @@ class mono_fm_joint_inpaint(mono_fm_joint):
         if features is not None:
             for i in range(5):
                 loss_dict[("feature_regularization_loss", i)] = \
-                    self.get_feature_regularization_loss(features[i], target) / (2 ** i) / 5
+                    self.get_feature_regularization_loss(features[i], target) * (1.0 / ((2 ** i) * 5))     # (/ 2^i / 5: exact powers of two times 0.2, one launch)
             fused = self._fused_feature_metric(inputs, outputs, features[0]) \
                 if self._fused_features_possible(inputs, self.Encoder) else None
             if fused is not None:
