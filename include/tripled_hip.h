@@ -305,6 +305,13 @@ int td_conv3x3_wgrad(const void* dy, const void* x, int B, int Ho, int Wo, int C
 long long td_conv1x1_wgrad_workspace_floats(long long M, int K, int N);
 int td_conv1x1_wgrad(const void* dy, const void* x, long long M, int K, int N, int Hi, int Wi, int stride, int dw_dtype, void* dw,
                      float* workspace, td_stream_t stream);
+/* n weight gradients in few launches: problem i == td_conv1x1_wgrad(dy[i], x[i], M[i], K[i], N[i], Hi[i], Wi[i], stride[i], dw_dtype[i],
+ * dw[i], workspace[i]), bit for bit (same tiling / row ranges / summation order); all array arguments are HOST arrays of length n
+ * (<= 4096).  A training step has ~90 independent 1x1 weight gradients that nothing needs before the optimiser step: enqueued by
+ * the autograd nodes and launched together they stop being ~180 latency-bound launches (tripled_amd.ops.deferred_wgrads). */
+int td_conv1x1_wgrad_group(int n, const void* const* dy, const void* const* x, const long long* M, const int* K, const int* N,
+                           const int* Hi, const int* Wi, const int* stride, const int* dw_dtype, void* const* dw,
+                           float* const* workspace, td_stream_t stream);
 int td_bn_fwd_from_partials(const void* x, const void* residual, int dtype, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int relu, long long M,
                             int groups, int C, float* partials, int stat_rows, void* y, float* save_mean,

@@ -66,6 +66,7 @@ def test_argument_validation_without_gpu():
     assert lib.td_maxpool5_bwd_add(None, None, None, 1, 1, 8, 8, 8, None, None) == -1
     assert lib.td_conv1x1_fwd_sum(None, None, 64, 64, 64, None, None, None, None) == -1
     assert lib.td_gather_flat(None, None, None, 0, 1, None, None) == -1
+    assert lib.td_conv1x1_wgrad_group(1, None, None, None, None, None, None, None, None, None, None, None, None) == -1
     # round-4 entry points (fused bottleneck)
     assert lib.td_bn_partial_rows(0, 1, 64) == 0 and lib.td_bn_partial_rows(92160, 1, 64) >= 1
     assert lib.td_bn_partial_rows(1440, 1, 512) <= 16            # wide, short layers: the GEMM prologue finishes them directly

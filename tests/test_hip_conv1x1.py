@@ -226,3 +226,48 @@ def test_conv3x3_implicit_gemm(B, Hi, Wi, C, N, stride, pad, groups):
     ref_s, ref_q = rows.sum(1).cpu(), (rows * rows).sum(1).cpu()
     assert torch.allclose(sums[..., 0], ref_s, rtol=1e-5, atol=1e-3 * float(ref_s.abs().max()) + 1e-6)
     assert torch.allclose(sums[..., 1], ref_q, rtol=1e-5, atol=1e-6)
+
+
+def test_grouped_weight_gradients_equal_the_single_launches(monkeypatch):
+    """td_conv1x1_wgrad_group over ALL shapes of SHAPES at once (two dtypes: 24 problems, and again 2 x 24 = 48 > the 40 of one
+    launch) against td_conv1x1_wgrad one by one: the grouped form keeps every problem's tiling, row ranges and summation order,
+    so the results are EQUAL bit for bit; and ops.deferred_wgrads() routes an autograd backward through it."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import native, ops
+    lib = native.load()
+    probs = []
+    for rep in range(2):
+        for (B, Hi, Wi, K, N, stride, groups) in SHAPES:
+            for dt in (torch.bfloat16, torch.float32):
+                g = torch.Generator().manual_seed(len(probs))
+                Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+                x = torch.randn(B, K, Hi, Wi, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+                dy = torch.randn(B, N, Ho, Wo, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+                w = torch.empty(N, K, 1, 1, device="cuda", dtype=dt)
+                probs.append((dy, x, w, B * Ho * Wo, K, N, Hi, Wi, stride))
+    single = [ops.conv1x1_wgrad(*p) for p in probs]
+    with ops.wgrad_group() as grp:                                         # "node" scope: tensors back at once, written at the exit
+        node = [ops.conv1x1_wgrad(*p) for p in probs]
+        assert len(grp.items) == (48 if ops.WGRAD_GROUP == "node" else 0)
+    torch.cuda.synchronize()
+    for a, b in zip(single, node):
+        assert torch.equal(a, b)
+    assert all(bool(torch.isfinite(a.float()).all()) for a in single)
+    for p in probs:
+        p[2].requires_grad_(True)
+    monkeypatch.setattr(ops, "WGRAD_GROUP", "step")
+    with ops.deferred_wgrads():                                            # "step" scope: autograd gets no gradient ...
+        with ops.wgrad_group() as inner:                                   # (a node scope inside leaves the step's queue in place)
+            assert all(ops.conv1x1_wgrad(*p) is None for p in probs)
+        assert not inner.items and all(p[2].grad is None for p in probs)
+    torch.cuda.synchronize()
+    for a, p in zip(single, probs):                                        # ... the exit of the block stores it
+        assert torch.equal(a, p[2].grad)
+    with ops.deferred_wgrads():                                            # a weight used twice, and one with a gradient already
+        ops.conv1x1_wgrad(*probs[0]), ops.conv1x1_wgrad(*probs[0])
+    torch.cuda.synchronize()
+    assert torch.equal(probs[0][2].grad, (single[0] + single[0]) + single[0])
+    monkeypatch.setattr(ops, "WGRAD_GROUP", "off")
+    with ops.wgrad_group() as grp:
+        off = ops.conv1x1_wgrad(*probs[1])
+    assert not grp.items and torch.equal(off, single[1])

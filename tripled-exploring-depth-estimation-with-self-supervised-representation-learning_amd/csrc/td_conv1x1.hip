@@ -382,16 +382,15 @@ __device__ __forceinline__ cv_bf16x8 wg_frag(const unsigned char* tile, int col0
   return __builtin_bit_cast(cv_bf16x8, v);
 }
 
-__global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_kernel(
+constexpr int WG_TILE_BYTES = WG_T * WG_PITCH, WG_STAGE = 2 * WG_TILE_BYTES, WG_LDS_BYTES = 2 * WG_STAGE;
+
+// one workgroup of the weight gradient: tile / row range L of the problem (dy, x) -> its fp32 partial tile in the slab buffer
+__device__ __forceinline__ void wgrad_block(
     const __hip_bfloat16* __restrict__ dy, const __hip_bfloat16* __restrict__ x, float* __restrict__ part, long long M, int K, int N,
-    int rows_per_split, int tiles_n, int tiles_k, ConvRows geom) {
-  constexpr int TILE_BYTES = WG_T * WG_PITCH, STAGE = 2 * TILE_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    int rows_per_split, int tiles_n, int tiles_k, ConvRows geom, int L, unsigned char* lds) {
+  constexpr int TILE_BYTES = WG_TILE_BYTES, STAGE = WG_STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid >> 1, wk = wid & 1;
-  // all (n, k) tiles of one row range read the same rows of dY and X: with the round-robin dispatch every XCD would pull every
-  // row range through its own L2 (8 x the operand bytes over the fabric); the remap gives each XCD a contiguous run of ranges
-  const int L = cv_xcd_tile(blockIdx.x, gridDim.x);
   const int nt = L % tiles_n, kt = (L / tiles_n) % tiles_k, sp = L / (tiles_n * tiles_k);
   const int n0 = nt * WG_T, k0 = kt * WG_T;
   const long long m_lo = (long long)sp * rows_per_split;
@@ -458,6 +457,45 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_kernel(
   for (int r = 0; r < 16; ++r) out[(size_t)((r & 3) + 8 * (r >> 2)) * K] = acc[r];
 }
 
+__global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_kernel(
+    const __hip_bfloat16* __restrict__ dy, const __hip_bfloat16* __restrict__ x, float* __restrict__ part, long long M, int K, int N,
+    int rows_per_split, int tiles_n, int tiles_k, ConvRows geom) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WG_LDS_BYTES];
+  // all (n, k) tiles of one row range read the same rows of dY and X: with the round-robin dispatch every XCD would pull every
+  // row range through its own L2 (8 x the operand bytes over the fabric); the remap gives each XCD a contiguous run of ranges
+  wgrad_block(dy, x, part, M, K, N, rows_per_split, tiles_n, tiles_k, geom, cv_xcd_tile(blockIdx.x, gridDim.x), lds);
+}
+
+// ---- grouped form: the weight gradients of MANY 1x1 convolutions in one launch (round 4).  A training step has ~90 of them; each
+// is a latency-bound launch of 13-35 us plus its slab sum (5.6 us), and nothing downstream needs any of them before the optimiser
+// runs, so the autograd nodes only ENQUEUE their problem (tripled_amd.ops.deferred_wgrads) and one grouped launch per <= 40 problems
+// runs them side by side: the per-problem tiling, row ranges and summation order are exactly those of the single form (bit-equal).
+constexpr int WG_GROUP_MAX = 40;
+struct WgProblem {
+  const __hip_bfloat16* dy;
+  const __hip_bfloat16* x;
+  float* part;
+  long long M;
+  int K, N, rows_per_split, tiles_n, tiles_k;
+  ConvRows geom;
+};
+struct WgGroupArgs {
+  WgProblem p[WG_GROUP_MAX];
+  int first_block[WG_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(CV_THREADS, 2) void conv1x1_wgrad_group_kernel(const WgGroupArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WG_LDS_BYTES];
+  const int L = cv_xcd_tile(blockIdx.x, gridDim.x);       // XCD-contiguous runs of blocks, i.e. of whole row ranges of a problem
+  int lo = 0, hi = a.n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.first_block[mid] <= L) lo = mid; else hi = mid;
+  }
+  const WgProblem& q = a.p[lo];
+  wgrad_block(q.dy, q.x, q.part, q.M, q.K, q.N, q.rows_per_split, q.tiles_n, q.tiles_k, q.geom, L - a.first_block[lo], lds);
+}
+
 // dW = sum over the P slabs, in a fixed order: a block owns 64 consecutive elements (16 float4 columns) and splits the slabs
 // over 16 lanes groups (p = g, g + 16, ...), combined through LDS -- a 64 x 64 weight with 360 slabs is 64 blocks of 23-deep
 // loops instead of 4 blocks of 360-deep ones.
@@ -488,6 +526,56 @@ __global__ __launch_bounds__(TD_THREADS) void conv1x1_wgrad_reduce_kernel(const 
       *reinterpret_cast<uint2*>(dw + i) = o;
     } else {
       *reinterpret_cast<float4*>(dw + i) = a;
+    }
+  }
+}
+
+// grouped slab sum: block b of problem p handles 64 consecutive elements exactly like conv1x1_wgrad_reduce_kernel
+constexpr int RD_GROUP_MAX = 96;
+struct RdProblem {
+  const float* part;
+  void* dw;
+  long long NK;
+  int P, bf16;
+};
+struct RdGroupArgs {
+  RdProblem p[RD_GROUP_MAX];
+  int first_block[RD_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(TD_THREADS) void conv1x1_wgrad_reduce_group_kernel(const RdGroupArgs a) {
+  __shared__ float4 red[16][16];
+  int lo = 0, hi = a.n;
+  const int b = (int)blockIdx.x;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.first_block[mid] <= b) lo = mid; else hi = mid;
+  }
+  const RdProblem& q = a.p[lo];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long long i = ((long long)(b - a.first_block[lo]) * 16 + c) * 4;
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < q.NK) {
+    for (int p = g; p < q.P; p += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(q.part + (size_t)p * q.NK + i);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+  }
+  red[g][c] = s4;
+  __syncthreads();
+  if (g == 0 && i < q.NK) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 v = red[j][c];
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    if (q.bf16) {
+      uint2 o;
+      o.x = (unsigned)f2bf(s4.x) | ((unsigned)f2bf(s4.y) << 16);
+      o.y = (unsigned)f2bf(s4.z) | ((unsigned)f2bf(s4.w) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<__hip_bfloat16*>(q.dw) + i) = o;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(q.dw) + i) = s4;
     }
   }
 }
@@ -677,5 +765,68 @@ extern "C" int td_conv1x1_wgrad(const void* dy, const void* x, long long M, int 
   else
     hipLaunchKernelGGL((td::conv1x1_wgrad_reduce_kernel<float>), dim3(blocks), dim3(TD_THREADS), 0, st, (const float*)workspace, P_eff, NK,
                        (float*)dw);
+  return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}
+
+// Grouped weight gradients: problem i is exactly td_conv1x1_wgrad(dy[i], x[i], M[i], K[i], N[i], Hi[i], Wi[i], stride[i], dw_dtype[i],
+// dw[i], workspace[i]) -- same tiling, same row ranges, same summation order, bit-equal results -- but <= 40 problems share a launch
+// (and <= 96 slab sums).  All array arguments are HOST arrays of length n.
+extern "C" int td_conv1x1_wgrad_group(int n, const void* const* dy, const void* const* x, const long long* M, const int* K, const int* N,
+                                      const int* Hi, const int* Wi, const int* stride, const int* dw_dtype, void* const* dw,
+                                      float* const* workspace, td_stream_t stream) {
+  if (n < 0 || (n > 0 && (!dy || !x || !M || !K || !N || !Hi || !Wi || !stride || !dw_dtype || !dw || !workspace))) return TD_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    if (!dy[i] || !x[i] || !dw[i] || !workspace[i] || M[i] <= 0 || K[i] <= 0 || N[i] <= 0 || K[i] % 64 != 0 || N[i] % 64 != 0 || stride[i] < 1)
+      return TD_ERR_BAD_ARG;
+    if (dw_dtype[i] != TD_DTYPE_BF16 && dw_dtype[i] != TD_DTYPE_F32) return TD_ERR_UNSUPPORTED;
+    if (M[i] * (long long)(K[i] > N[i] ? K[i] : N[i]) >= (1ll << 40)) return TD_ERR_UNSUPPORTED;
+    if (stride[i] > 1) {
+      if (Hi[i] <= 0 || Wi[i] <= 0) return TD_ERR_BAD_ARG;
+      const int Ho = (Hi[i] - 1) / stride[i] + 1, Wo = (Wi[i] - 1) / stride[i] + 1;
+      if (M[i] % ((long long)Ho * Wo) != 0) return TD_ERR_BAD_ARG;
+    }
+  }
+  int P_eff[4096];
+  if (n > 4096) return TD_ERR_UNSUPPORTED;
+  for (int base = 0; base < n; base += td::WG_GROUP_MAX) {
+    td::WgGroupArgs a;
+    a.n = n - base < td::WG_GROUP_MAX ? n - base : td::WG_GROUP_MAX;
+    long long blocks = 0;
+    for (int j = 0; j < a.n; ++j) {
+      const int i = base + j;
+      td::ConvRows geom = {0, 0, 0, 0, 1};
+      if (stride[i] > 1) {
+        const int Ho = (Hi[i] - 1) / stride[i] + 1, Wo = (Wi[i] - 1) / stride[i] + 1;
+        geom = {Wo, Ho * Wo, Wi[i], Hi[i] * Wi[i], stride[i]};
+      }
+      const int P = td::wg_splits(M[i], K[i], N[i]);
+      long long rps = (M[i] + P - 1) / P;
+      rps = (rps + td::WG_T - 1) / td::WG_T * td::WG_T;
+      P_eff[i] = (int)((M[i] + rps - 1) / rps);
+      td::WgProblem& q = a.p[j];
+      q.dy = (const __hip_bfloat16*)dy[i]; q.x = (const __hip_bfloat16*)x[i]; q.part = workspace[i]; q.M = M[i]; q.K = K[i]; q.N = N[i];
+      q.rows_per_split = (int)rps; q.tiles_n = N[i] / td::WG_T; q.tiles_k = K[i] / td::WG_T; q.geom = geom;
+      a.first_block[j] = (int)blocks;
+      blocks += (long long)q.tiles_n * q.tiles_k * P_eff[i];
+      if (blocks > 0x7fffffffll) return TD_ERR_UNSUPPORTED;
+    }
+    for (int j = a.n; j <= td::WG_GROUP_MAX; ++j) a.first_block[j] = (int)blocks;
+    hipLaunchKernelGGL(td::conv1x1_wgrad_group_kernel, dim3((unsigned)blocks), dim3(td::CV_THREADS), 0, st, a);
+  }
+  for (int base = 0; base < n; base += td::RD_GROUP_MAX) {
+    td::RdGroupArgs a;
+    a.n = n - base < td::RD_GROUP_MAX ? n - base : td::RD_GROUP_MAX;
+    long long blocks = 0;
+    for (int j = 0; j < a.n; ++j) {
+      const int i = base + j;
+      td::RdProblem& q = a.p[j];
+      q.part = workspace[i]; q.dw = dw[i]; q.NK = (long long)N[i] * K[i]; q.P = P_eff[i]; q.bf16 = dw_dtype[i] == TD_DTYPE_BF16;
+      a.first_block[j] = (int)blocks;
+      blocks += (q.NK / 4 + 15) / 16;
+    }
+    for (int j = a.n; j <= td::RD_GROUP_MAX; ++j) a.first_block[j] = (int)blocks;
+    hipLaunchKernelGGL(td::conv1x1_wgrad_reduce_group_kernel, dim3((unsigned)blocks), dim3(TD_THREADS), 0, st, a);
+  }
   return hipGetLastError() == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "td_conv3x3_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "td_conv1x1_wgrad_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _I]),
     "td_conv1x1_wgrad": (_I, [_P, _P, ctypes.c_longlong, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "td_conv1x1_wgrad_group": (_I, [_I, _PTRARR, _PTRARR, _LLARR, _IARR, _IARR, _IARR, _IARR, _IARR, _IARR, _PTRARR, _PTRARR, _P]),
     "td_bn_fwd_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _I, ctypes.c_longlong, _I, _I, _P, _I, _P, _P, _P, _P]),
     "td_bias_act_workspace_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I]),
     "td_bias_act_fwd": (_I, [_P, _P, _I, _I, ctypes.c_longlong, _I, _I, _P, _P]),

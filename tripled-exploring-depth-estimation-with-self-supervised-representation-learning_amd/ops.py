@@ -4,6 +4,8 @@ These are the fused replacements for the reference's unfused loss ops; each docs
 the reference lines it stands in for.  All launches go to torch's current HIP stream and do
 not synchronise, so a training step that uses them can be captured in a HIP graph.
 """
+import os
+
 import torch
 
 from . import native
@@ -333,6 +335,11 @@ class _CRP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        with wgrad_group():      # the node's 1x1 weight gradients leave as one grouped launch at the end
+            return _CRP._backward(ctx, g)
+
+    @staticmethod
+    def _backward(ctx, g):
         lib = native.load()
         strm = native.stream()
         n = ctx.n
@@ -346,11 +353,7 @@ class _CRP(torch.autograd.Function):
         dws = [None] * n
         for i in reversed(range(n)):
             w, pooled, idx = ws[i], saved[2 * i], saved[2 * i + 1]
-            dw = torch.empty_like(w)
-            wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, C, C), device=g.device, dtype=torch.float32)
-            native.check(lib.td_conv1x1_wgrad(_raw(g_top), _raw(pooled), M, C, C, H, W, 1, native.DTYPE_CODES[w.dtype], _raw(dw),
-                                              native.ptr(wsw), strm), "td_conv1x1_wgrad")
-            dws[i] = dw
+            dws[i] = conv1x1_wgrad(g_top, pooled, w, M, C, C, H, W, 1)
             d_pool = torch.empty_like(g, memory_format=torch.channels_last)
             native.check(lib.td_conv1x1_dgrad(_raw(g_top), _raw(w), M, 1, C, C, None, _raw(d_pool), strm), "td_conv1x1_dgrad")
             g_prev = torch.empty_like(g, memory_format=torch.channels_last)
@@ -563,10 +566,7 @@ class _Conv1x1BatchNormAct(torch.autograd.Function):
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:      # weight gradient: hand-written MFMA kernel (transposed LDS reads, ordered slab sum)
             K, Hi, Wi = x.shape[1], x.shape[2], x.shape[3]
-            dw = torch.empty_like(w)
-            wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), device=x.device, dtype=torch.float32)
-            native.check(lib.td_conv1x1_wgrad(_raw(dyc), _raw(x), M, K, N, Hi, Wi, ctx.stride, native.DTYPE_CODES[w.dtype], _raw(dw),
-                                              native.ptr(wsw), native.stream()), "td_conv1x1_wgrad")
+            dw = conv1x1_wgrad(dyc, x, w, M, K, N, Hi, Wi, ctx.stride)
         return dx, dw, dgamma.to(weight.dtype), dbeta.to(weight.dtype), None, None, dres, None, None, None, None, None
 
 
@@ -646,6 +646,88 @@ def conv_bias_act(x, w, b, act=None):
     if not conv_bias_act_supported(x, w, b, act):
         raise native.NativeLibraryError("conv_bias_act needs bf16 channels_last HIP tensors, Cout in {8, 16, 32, 64, 128, 256}")
     return _ConvBiasAct.apply(x, w, b, act)
+
+
+# ---- weight gradients of the 1x1 convolutions: immediate, or enqueued and launched as one group ---------------------------
+_WGRAD_QUEUE = None          # the innermost active wgrad_group, or None
+WGRAD_GROUP = os.environ.get("TD_WGRAD_GROUP", "node")      # "node" | "step" | "off"
+
+
+class wgrad_group:
+    """A scope whose 1x1 weight gradients (conv1x1_wgrad) are ENQUEUED and launched together at its exit by
+    td_conv1x1_wgrad_group -- 2 launches per <= 40 problems instead of 2 per problem, bit-equal results.
+
+    ``assign=False`` (a backward node around its own three or four weight gradients: scope "node"): conv1x1_wgrad returns the
+    output tensor at once and the exit, still inside the node's backward, writes it -- autograd never sees an unwritten buffer.
+    ``assign=True`` (around a whole ``loss.backward()``: scope "step", TD_WGRAD_GROUP=step): a deferred node hands autograd NO
+    gradient for its weight (None); the exit computes the group and then stores (first use) or adds (a weight used twice) each
+    result into ``weight.grad`` itself.  Only leaf weights are deferred that way and per-parameter gradient hooks do not see
+    them, so tripled_amd.step.TrainStep allows it only with the flat parameter store and without the overlapped bucket engine.
+    Measured (profiles/r04/wgrad_group_v1.txt): "step" is SLOWER than no grouping -- at the end of backward every dz and x comes
+    from HBM again, while the immediate launches find them in L2 / MALL -- so "node" is the default."""
+
+    def __init__(self, assign=False, scope="node"):
+        self.assign, self.scope, self.items = assign, scope, []
+
+    def __enter__(self):
+        global _WGRAD_QUEUE
+        self.prev = _WGRAD_QUEUE
+        # an inner "node" scope inside an active "step" scope leaves the queue of the step in place
+        self.active = WGRAD_GROUP == self.scope and not (self.prev is not None and self.prev.assign)
+        if self.active:
+            _WGRAD_QUEUE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_QUEUE
+        if self.active:
+            _WGRAD_QUEUE = self.prev
+            if self.items and exc[0] is None:
+                flush_wgrads(self.items)
+        return False
+
+
+def deferred_wgrads():
+    """``with deferred_wgrads(): loss.backward()`` -- the "step" scope of wgrad_group (active under TD_WGRAD_GROUP=step)."""
+    return wgrad_group(assign=True, scope="step")
+
+
+def flush_wgrads(queue):
+    import ctypes
+    lib = native.load()
+    n = len(queue)
+    P, LL, I = (ctypes.c_void_p * n), (ctypes.c_longlong * n), (ctypes.c_int * n)
+    dy, x, dw, ws = P(), P(), P(), P()
+    for i, q in enumerate(queue):
+        dy[i], x[i], dw[i], ws[i] = q["dy"].data_ptr(), q["x"].data_ptr(), q["dw"].data_ptr(), q["ws"].data_ptr()
+    native.check(lib.td_conv1x1_wgrad_group(n, dy, x, LL(*[q["M"] for q in queue]), I(*[q["K"] for q in queue]),
+                                            I(*[q["N"] for q in queue]), I(*[q["Hi"] for q in queue]), I(*[q["Wi"] for q in queue]),
+                                            I(*[q["stride"] for q in queue]), I(*[native.DTYPE_CODES[q["dw"].dtype] for q in queue]),
+                                            dw, ws, native.stream()), "td_conv1x1_wgrad_group")
+    for q in queue:
+        w = q["w"]
+        if w is None:
+            continue
+        if w.grad is None:
+            w.grad = q["dw"]
+        else:
+            w.grad.add_(q["dw"])
+
+
+def conv1x1_wgrad(dz, inp, w, M, K, N, Hi, Wi, stride):
+    """dW of a 1x1 convolution (td_conv1x1_wgrad) for an autograd backward to return: launched now, or enqueued in the
+    innermost wgrad_group -- which returns the tensor its exit will write ("node" scope), or None for a leaf weight whose
+    .grad the exit fills in ("step" scope)."""
+    lib = native.load()
+    dw = torch.empty_like(w)
+    wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), device=dz.device, dtype=torch.float32)
+    q = _WGRAD_QUEUE
+    if q is not None and (not q.assign or (w.is_leaf and w.requires_grad)):
+        q.items.append(dict(dy=dz, x=inp, dw=dw, ws=wsw, w=w if q.assign else None, M=M, K=K, N=N, Hi=Hi, Wi=Wi, stride=stride))
+        return None if q.assign else dw
+    native.check(lib.td_conv1x1_wgrad(_raw(dz), _raw(inp), M, K, N, Hi, Wi, stride, native.DTYPE_CODES[w.dtype], _raw(dw),
+                                      native.ptr(wsw), native.stream()), "td_conv1x1_wgrad")
+    return dw
 
 
 def conv3x3_wgrad_wins(B, Ho, Wo, C, N, stride):
@@ -763,6 +845,11 @@ class _Bottleneck(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with wgrad_group():      # the node's 1x1 weight gradients leave as one grouped launch at the end
+            return _Bottleneck._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         lib = native.load()
         strm = native.stream()
         (x, w1, w2, w3, g1, b1, g2, b2, g3, b3, wd, gd, bd, z1, a1, z2, a2, z3, y, zd, mean1, invstd1, mean2, invstd2, mean3,
@@ -777,12 +864,7 @@ class _Bottleneck(torch.autograd.Function):
         if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
-        def wgrad(dz, inp, w, M, K, N, Hi, Wi, s_):
-            dw = torch.empty_like(w)
-            wsw = torch.empty(lib.td_conv1x1_wgrad_workspace_floats(M, K, N), **f32)
-            native.check(lib.td_conv1x1_wgrad(_raw(dz), _raw(inp), M, K, N, Hi, Wi, s_, native.DTYPE_CODES[w.dtype], _raw(dw),
-                                              native.ptr(wsw), strm), "td_conv1x1_wgrad")
-            return dw
+        wgrad = conv1x1_wgrad          # immediate, or enqueued inside deferred_wgrads()
 
         def bn_bwd(dyy, zz, yy, gamma, beta, mean, invstd, relu, M, C, want_res):
             dz = torch.empty_like(zz, memory_format=torch.channels_last)

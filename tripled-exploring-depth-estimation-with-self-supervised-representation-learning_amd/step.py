@@ -102,7 +102,15 @@ class TrainStep:
         # from the reference's left-to-right Python sum by fp32 rounding of the summation order only)
         vals = list(means.values())
         total = vals[0] if len(vals) == 1 else torch.stack(vals).sum()
-        total.backward()
+        if self.flat is not None and self.reducer is None and self.device.type == "cuda":
+            # TD_WGRAD_GROUP=step: nothing reads a weight gradient before collect(), so the 1x1 weight gradients of the whole
+            # step may be enqueued and launched together (tripled_amd.ops.deferred_wgrads; a no-op under the default "node"
+            # scope, where every fused backward node groups its own -- the faster of the two, see ops.wgrad_group)
+            from . import ops
+            with ops.deferred_wgrads():
+                total.backward()
+        else:
+            total.backward()
         if self.flat is not None:
             self.flat.collect()
         self.loss = total.detach()
