@@ -602,6 +602,11 @@ def main():
                 "step_mode": used_mode, "step_mode_trials_ms": trials or None,
                 "h2d_in_step": args.h2d or False, "extractor_tail_pruned": bool(m.get("prune_extractor_tail", False)),
                 "capture_stream": CAPTURE_STREAM if graphed else None,
+                # tripled_amd.streams: auto-encoder and pose network on side streams beside the depth chain (parallel branches
+                # of the captured graph); off under the overlapped bucket engine, whose hooks assume one backward stream
+                "branch_streams": bool(__import__("tripled_amd.streams", fromlist=["ENABLED"]).ENABLED and getattr(model, "branch_streams", True)
+                                       and m["name"] in ("mono_fm_joint_inpaint_disentangle",
+                                                         "mono_fm_joint_inpaint_disentangle_distill_sep_colorize")),
                 "fallbacks": sum(dispatch.fallbacks.values()), "td_abi_calls_per_step": td_calls_per_step,
                 "loss_after_warmup": round(loss_after_warmup, 6), "final_loss": round(final_loss, 6), "valid": True},
         }

@@ -4,6 +4,7 @@ the classes the BASELINE configs name -- ``mono_fm_joint_inpaint`` (base),
 ``mono_fm_joint_inpaint_disentangle_distill_sep_colorize`` (the all-aux-heads config).  The
 reference's six other ablation classes are out of scope (SURVEY.md section 2.1 #3)."""
 import argparse
+import os
 
 import torch
 import torch.nn as nn
@@ -13,6 +14,15 @@ from ..registry import MONO
 from ..mono_fm_joint.net import mono_fm_joint, resize_bilinear
 from ..networks import ColorDecoder, Conv1x1, DepthDecoder, Encoder, IdentityPartial, bn_groups
 from .color_conversions import rgb2lab
+
+
+def _streams():
+    """tripled_amd.streams where the HIP package is importable (the model files also run stand-alone on the CPU)."""
+    try:
+        from tripled_amd import streams
+    except ImportError:
+        return None
+    return streams
 
 
 @MONO.register_module
@@ -81,15 +91,38 @@ class mono_fm_joint_inpaint(mono_fm_joint):
             loss = torch.sum(loss * hole) / torch.sum(hole)
         return loss / len(opt.scales) * opt.get("img_reconstruct_weight", 1)
 
+    def _feature_regularization(self, features, target, i):
+        # (/ 2^i / 5: exact powers of two times 0.2, one launch)
+        return self.get_feature_regularization_loss(features[i], target) * (1.0 / ((2 ** i) * 5))
+
+    def _autoencoder_losses(self, inputs, auto_out, features):
+        """The loss terms that read nothing but the auto-encoder's own outputs (feature regularisation, reference :52-55, and
+        the masked reconstruction of every scale, :80-91) can be computed where the auto-encoder runs -- on its side stream,
+        next to the depth chain -- and handed to compute_losses, which puts them into the loss dictionary at their usual places.
+        Opt-in (TD_EARLY_AUX_LOSSES=1): measured 3.4 ms SLOWER per step than computing them after the join (30.6 against 27.3 ms,
+        profiles/r04/branch_streams_v1.txt) -- the graph's side branch then ends in 9 small loss nodes whose backward heads the
+        auto-encoder's backward chain, and the replay serialises more of the two chains."""
+        if features is None or os.environ.get("TD_EARLY_AUX_LOSSES", "0") != "1":
+            return {}
+        early = {}
+        target = inputs[("color", 0, 0)]
+        for i in range(5):
+            early[("feature_regularization_loss", i)] = self._feature_regularization(features, target, i)
+        if self.opt.get("img_reconstruct_weight", 1) != 0:
+            for scale in self.opt.scales:
+                early[("img_reconstruct_loss", scale)] = self._masked_reconstruction(inputs, auto_out, scale)
+        return early
+
     def compute_losses(self, inputs, outputs, features):
         """reference :47-133."""
         opt = self.opt
         loss_dict = {}
         target = inputs[("color", 0, 0)]
+        early = self.__dict__.pop("_branch_losses", None) or {}
         if features is not None:
             for i in range(5):
-                loss_dict[("feature_regularization_loss", i)] = \
-                    self.get_feature_regularization_loss(features[i], target) * (1.0 / ((2 ** i) * 5))     # (/ 2^i / 5: exact powers of two times 0.2, one launch)
+                key = ("feature_regularization_loss", i)
+                loss_dict[key] = early[key] if key in early else self._feature_regularization(features, target, i)
             fused = self._fused_feature_metric(inputs, outputs, features[0]) \
                 if self._fused_features_possible(inputs, self.Encoder) else None
             if fused is not None:
@@ -104,7 +137,8 @@ class mono_fm_joint_inpaint(mono_fm_joint):
         ctx = self._begin_step(inputs)
         for scale in opt.scales:
             if features is not None and opt.get("img_reconstruct_weight", 1) != 0:
-                loss_dict[("img_reconstruct_loss", scale)] = self._masked_reconstruction(inputs, outputs, scale)
+                key = ("img_reconstruct_loss", scale)
+                loss_dict[key] = early[key] if key in early else self._masked_reconstruction(inputs, outputs, scale)
             self._photometric_scale(ctx, inputs, outputs, scale, loss_dict)
             self._smooth_scale(ctx, outputs, scale, loss_dict)
         return loss_dict
@@ -176,6 +210,22 @@ class mono_fm_joint_inpaint_disentangle(mono_fm_joint_inpaint):
 
     def forward(self, inputs):
         opt = self.opt
+        fork = (self.training and getattr(self, "branch_streams", True) and _streams() is not None
+                and _streams().enabled(inputs["color_aug", 0, 0]))
+        if fork:
+            # the auto-encoder and (without use_pfp) the pose network need only the input images: queued on two side streams,
+            # they overlap the depth chain below, forward and backward (tripled_amd.streams).  Queueing them after the depth
+            # chain instead (from an event taken here) measured the same within noise (profiles/r04/branch_streams_v1.txt).
+            dev = inputs["color_aug", 0, 0].device
+            auto, auto_out = _streams().Branch(dev, 0), {}
+            with auto:
+                features = self._autoencode(inputs, auto_out, masked=False)
+                early = self._autoencoder_losses(inputs, auto_out, features)
+            pose = None
+            if not opt.get("use_pfp", False):
+                pose = _streams().Branch(dev, 1)
+                with pose:
+                    pose_out = self.predict_poses(inputs)
         scene = self.DepthEncoder(inputs["color_aug", 0, 0])
         depth_emb = [getattr(self, "depth_skip_layer_{}".format(i))(scene[i])
                      for i in range(len(opt.disentangle_layers))]
@@ -190,6 +240,18 @@ class mono_fm_joint_inpaint_disentangle(mono_fm_joint_inpaint):
             color_emb = [scene[i][:, scene[i].size(1) // 2:] if split else scene[i]
                          for i, split in enumerate(opt.disentangle_layers)]
         outputs = self.ColorDecoder(color_emb, outputs, skip_layers=opt.color_skip_layers)
+        if fork:
+            if pose is None:
+                feats = {f: resize_bilinear(inputs["color_aug", f, 0], [192, 640]) for f in opt.frame_ids[1:]}
+                feats[0] = resize_bilinear(outputs[("auto_res_img", 0, 0)].float(), [192, 640])
+                pose_out = self.predict_poses(inputs, feats)
+            else:
+                pose.join(pose_out)
+            outputs.update(pose_out)
+            auto.join(features, auto_out, early)
+            outputs.update(auto_out)
+            self._branch_losses = early
+            return outputs, self.compute_losses(inputs, outputs, features)
         if opt.get("use_pfp", False):
             feats = {f: resize_bilinear(inputs["color_aug", f, 0], [192, 640]) for f in opt.frame_ids[1:]}
             feats[0] = resize_bilinear(outputs[("auto_res_img", 0, 0)].float(), [192, 640])
@@ -231,25 +293,59 @@ class mono_fm_joint_inpaint_disentangle_distill_sep_colorize(mono_fm_joint_inpai
 
     def forward(self, inputs):
         opt = self.opt
+        img = inputs[("color", 0, 0)]
+        fork = (self.training and getattr(self, "branch_streams", True) and _streams() is not None
+                and _streams().enabled(img))
+        if fork:
+            # auto-encoder, pose network and (unconditioned) colourisation encoder need only the input images: on side
+            # streams, beside the depth chain (tripled_amd.streams; see mono_fm_joint_inpaint_disentangle.forward)
+            auto, auto_out = _streams().Branch(img.device, 0), {}
+            with auto:
+                features = self._autoencode(inputs, auto_out, masked=False)
+                early = self._autoencoder_losses(inputs, auto_out, features)
+            pose = _streams().Branch(img.device, 1)
+            with pose:
+                pose_out = self.predict_poses(inputs)
+            grey_emb = None
+            if not opt.get("cond_encoder", False):
+                colorize = _streams().Branch(img.device, 2)
+                with colorize:
+                    lab = self._lab(img)
+                    grey_emb = self.ColorizeEncoder(lab[:, 0:1].expand(-1, 3, -1, -1), None)
         scene = self.DepthEncoder(inputs["color_aug", 0, 0])
         depth_emb = [scene[i][:, :scene[i].size(1) // 2] if split else scene[i]
                      for i, split in enumerate(opt.disentangle_layers)]
         outputs = self.DepthDecoder(depth_emb)
         if not self.training:
             return outputs
+        if fork:
+            pose.join(pose_out)
+            outputs.update(pose_out)
+            if grey_emb is None:
+                lab = self._lab(img)
+                grey_emb = self.ColorizeEncoder(lab[:, 0:1].expand(-1, 3, -1, -1), depth_emb)
+            else:
+                colorize.join(lab, grey_emb)
+            outputs = self.ColorizeDecoder(grey_emb, outputs)
+            inputs["gt_ab"] = lab[:, 1:]
+            auto.join(features, auto_out, early)
+            outputs.update(auto_out)
+            self._branch_losses = early
+            return outputs, self.compute_losses(inputs, outputs, features)
         outputs.update(self.predict_poses(inputs))
-        img = inputs[("color", 0, 0)]
-        if img.is_cuda:
-            from tripled_amd import ops
-            lab = ops.rgb2lab(img, 50.0, 50.0, 110.0)      # one HIP pass (color_conversions.py: ~25 element-wise launches)
-        else:
-            lab = self.to_lab(img, argparse.Namespace(l_cent=50.0, l_norm=50.0, ab_norm=110.0))
+        lab = self._lab(img)
         grey = lab[:, 0:1].expand(-1, 3, -1, -1)
         grey_emb = self.ColorizeEncoder(grey, depth_emb if opt.get("cond_encoder", False) else None)
         outputs = self.ColorizeDecoder(grey_emb, outputs)
         inputs["gt_ab"] = lab[:, 1:]
         features = self._autoencode(inputs, outputs, masked=False)
         return outputs, self.compute_losses(inputs, outputs, features)
+
+    def _lab(self, img):
+        if img.is_cuda:
+            from tripled_amd import ops
+            return ops.rgb2lab(img, 50.0, 50.0, 110.0)      # one HIP pass (color_conversions.py: ~25 element-wise launches)
+        return self.to_lab(img, argparse.Namespace(l_cent=50.0, l_norm=50.0, ab_norm=110.0))
 
     def compute_colorization_loss(self, inputs, outputs):
         """reference :310-323."""

@@ -62,6 +62,10 @@ class TrainStep:
         clip = cfg.optimizer_config.get("grad_clip", None)
         self.max_norm = clip["max_norm"] if clip else None
         self.reducer = getattr(model, "reducer", None)
+        if self.reducer is not None and getattr(self.reducer, "overlap", False):
+            # the overlapped bucket engine launches its collectives from per-parameter hooks on the stream it was built on:
+            # keep every backward node on that stream (tripled_amd.streams forks the sub-networks otherwise)
+            inner.branch_streams = False
         self.flat = None
         self.device = torch.device(device) if device is not None else batch["K"].device
         on_gpu = self.device.type == "cuda"

@@ -1,0 +1,70 @@
+"""Independent sub-networks of one training step on concurrent HIP streams.
+
+The TripleD step holds three chains that meet only in the losses: the depth encoder / decoder (+ colour decoder), the pose
+network on the frame pairs, and the feature auto-encoder on the target image (reference: mono_fm_joint_inpaint/net.py:488-514
+runs them one after the other on the one CUDA stream).  Most of their kernels are latency-bound launches of <= 1 block per CU
+(the 14-20 us floor of the small GEMMs, the 3-6 us element-wise passes), so issuing the chains on separate
+streams lets the hardware fill one chain's tails and gaps with the other's work.  ``Branch`` is the fork / join:
+
+    with Branch(device, 0) as b:          # side stream 0 waits for the work already queued on the current stream
+        feats = encoder(img)              # ... queued on the side stream
+    ...                                   # the current stream goes on meanwhile
+    b.join(feats)                         # the current stream waits for the branch; its tensors are marked as used here
+
+The autograd engine replays every backward node on the stream its forward ran on and orders the streams itself, so the backward
+pass forks the same way.  Inside a HIP-graph capture the side streams join the capture at the fork and the chains become
+parallel branches of the graph.  ``join`` calls ``record_stream`` on the tensors that cross, which keeps the caching allocator
+from handing their blocks back to the side stream while the consumer may still read them.
+TD_BRANCH_STREAMS=0 turns the forks off (every chain on the current stream, in the reference's order)."""
+import os
+
+import torch
+
+ENABLED = os.environ.get("TD_BRANCH_STREAMS", "1") != "0"
+_side = {}
+
+
+def enabled(t):
+    return ENABLED and t.is_cuda
+
+
+def side_stream(device, idx):
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, idx)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=index)
+    return _side[key]
+
+
+def _tensors(tree):
+    if torch.is_tensor(tree):
+        yield tree
+    elif isinstance(tree, dict):
+        for v in tree.values():
+            yield from _tensors(v)
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            yield from _tensors(v)
+
+
+class Branch:
+    def __init__(self, device, idx):
+        self.stream = side_stream(device, idx)
+        self.scope = None
+
+    def __enter__(self):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.scope = torch.cuda.stream(self.stream)
+        self.scope.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.scope.__exit__(*exc)
+        return False
+
+    def join(self, *trees):
+        main = torch.cuda.current_stream()
+        main.wait_stream(self.stream)
+        for t in _tensors(trees):
+            if t.is_cuda:
+                t.record_stream(main)
