@@ -1,10 +1,16 @@
 """tripled_amd.streams: the three independent chains of the TripleD step on concurrent HIP streams give the step the serial
 order gives -- the forward losses to fp32 rounding of MIOpen's run-to-run summation order (the chains share no buffer), the
 gradients within the run-to-run spread MIOpen's order-dependent weight-gradient solvers have anyway."""
+import json
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _step(fork):
@@ -60,3 +66,51 @@ def test_branch_orders_the_streams_and_marks_the_tensors():
     assert torch.cuda.current_stream() != b.stream
     assert float((out["x"][0] + out["x"][1][0]).sum()) == (6.0 + 3.0) * (1 << 22)
     assert streams.side_stream(dev, 0) is b.stream and streams.side_stream(dev, 1) is not b.stream
+
+
+def test_a_branch_never_lands_on_the_current_stream():
+    """torch.cuda.Stream() cycles through a pool of 32 HIP streams: a caller-side stream created later can alias a cached side
+    stream.  Branch must then move to another stream (a fork onto the current stream, captured, gave hipGraphLaunch a node with
+    a duplicated dependency: segfault in the full test suite of round 4) -- checked eagerly and inside a capture."""
+    import tripled_amd  # noqa: F401
+    from tripled_amd import streams
+    dev = torch.device("cuda", 0)
+    first = streams.Branch(dev, 0).stream
+    seen = set()
+    for _ in range(40):                       # more than one round of the pool: every pooled stream is "current" once
+        cur = torch.cuda.Stream()
+        seen.add(int(cur.cuda_stream))
+        with torch.cuda.stream(cur):
+            b0, b1 = streams.Branch(dev, 0), streams.Branch(dev, 1)
+            ids = {int(cur.cuda_stream), int(b0.stream.cuda_stream), int(b1.stream.cuda_stream)}
+            assert len(ids) == 3 and 0 not in ids
+    assert int(first.cuda_stream) in seen     # the aliasing case did occur in the loop
+    cap = torch.cuda.Stream()
+    x = torch.ones(1 << 20, device=dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=cap):
+        with streams.Branch(dev, 0) as b:
+            y = x * 2.0
+        z = x + 1.0
+        b.join(y)
+        out = y + z
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert float(out.sum()) == 4.0 * (1 << 20)
+
+
+def test_bench_replays_the_forked_step_from_a_hip_graph():
+    """The product path: bench.py in a fresh process captures the cfg_kitti_tripleD step with the forks on (three parallel
+    branches in the HIP graph, forward and backward), replays it through both entries (TrainStep and Runner.run) and reports
+    a finite, moving loss with zero ATen fallbacks."""
+    env = dict(os.environ)
+    env.pop("TD_BRANCH_STREAMS", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-roofline", "--miopen-find", "off"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = line["config"]
+    assert c["branch_streams"] is True and c["hip_graph"] and c["valid"] and c["fallbacks"] == 0, c
+    assert line["runner_entry"]["ms_per_step"] > 0, line["runner_entry"]

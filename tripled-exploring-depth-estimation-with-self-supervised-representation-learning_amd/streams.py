@@ -28,12 +28,24 @@ def enabled(t):
     return ENABLED and t.is_cuda
 
 
-def side_stream(device, idx):
+def side_stream(device, idx, avoid=()):
+    """The cached side stream ``idx`` of ``device`` -- never one of ``avoid`` and never another index's stream.
+    torch.cuda.Stream() hands out a pool of 32 HIP streams per device round-robin, so a stream created here can BE the stream
+    the caller is on (a capture stream created 32 creations later): forking onto the current stream would record an event on
+    a stream and make the same stream wait for it, which inside a capture gives the next node the same dependency twice --
+    hipGraphLaunch of such a graph segfaulted (round 4: tests/test_hip_graph_step.py after ~300 other tests in the process)."""
     index = device.index if device.index is not None else torch.cuda.current_device()
     key = (index, idx)
-    if key not in _side:
-        _side[key] = torch.cuda.Stream(device=index)
-    return _side[key]
+    taken = {int(a.cuda_stream) for a in avoid} | {int(v.cuda_stream) for k, v in _side.items() if k[0] == index and k != key}
+    cached = _side.get(key)
+    tries = 0
+    while cached is None or int(cached.cuda_stream) in taken or int(cached.cuda_stream) == 0:
+        cached = torch.cuda.Stream(device=index)
+        tries += 1
+        if tries > 64:
+            raise RuntimeError("no free HIP stream for branch %d on device %d" % (idx, index))
+    _side[key] = cached
+    return cached
 
 
 def _tensors(tree):
@@ -49,7 +61,7 @@ def _tensors(tree):
 
 class Branch:
     def __init__(self, device, idx):
-        self.stream = side_stream(device, idx)
+        self.stream = side_stream(device, idx, avoid=(torch.cuda.current_stream(),))
         self.scope = None
 
     def __enter__(self):
@@ -64,7 +76,8 @@ class Branch:
 
     def join(self, *trees):
         main = torch.cuda.current_stream()
-        main.wait_stream(self.stream)
+        if int(main.cuda_stream) != int(self.stream.cuda_stream):      # (a join from another stream than the fork's)
+            main.wait_stream(self.stream)
         for t in _tensors(trees):
             if t.is_cuda:
                 t.record_stream(main)
