@@ -29,7 +29,9 @@ def _one_stream_in_the_long_test_process():
     parity; the forked step captured and replayed is tested through bench.py in a fresh process, the way the product runs it).
     Reason: replaying a forked graph that was captured ~300 tests into the pytest process segfaulted inside hipGraphLaunch
     (tests/test_hip_graph_step.py, first replay; the same test alone, bench.py and the train.py path replay their forked graphs
-    without fault) -- unresolved at the end of round 4, recorded in DESIGN.md section 6."""
+    without fault).  Probable cause (a pooled torch.cuda.Stream() aliasing the cached side stream) removed in streams.side_stream and
+    pinned by tests/test_streams_cpu.py + test_hip_streams.py; the confirming full-suite run with the forks on did not fit round 4's GPU
+    budget, so this default stays until it has been done once -- DESIGN.md section 13."""
     try:
         import tripled_amd  # noqa: F401
         from tripled_amd import streams
