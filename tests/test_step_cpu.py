@@ -120,3 +120,27 @@ def test_runner_iteration_reports_the_graphs_outputs_after_an_eager_iteration():
     assert float(out["log_vars"]["a"]) == 102.0 and it.eager_iterations == 1
     out = it(Model(), dict(data), True)
     assert float(out["log_vars"]["a"]) == 3.0
+
+
+def test_the_overlapped_bucket_engine_keeps_backward_on_one_stream():
+    """The overlapped engine launches its collectives from per-parameter hooks on the stream it was built on, so a model that
+    trains under it must not fork its sub-networks onto side streams (tripled_amd.streams); every other gradient exchange
+    (none, or the flat buffer's all-reduce after backward) leaves the forks as they are."""
+    model, step = _step()
+    cfg = ConfigDict(model=model.opt, optimizer=dict(type="Adam", lr=1e-4, weight_decay=0),
+                     optimizer_config=dict(grad_clip=None))
+    assert getattr(model, "branch_streams", True) is True
+
+    class _Wrapped(torch.nn.Module):
+        def __init__(self, module, overlap):
+            super().__init__()
+            self.module = module
+            self.reducer = type("Reducer", (), {"overlap": overlap})()
+
+        def forward(self, x):
+            return self.module(x)
+
+    TrainStep(_Wrapped(model, overlap=False), cfg, step.batch, None)
+    assert getattr(model, "branch_streams", True) is True
+    TrainStep(_Wrapped(model, overlap=True), cfg, step.batch, None)
+    assert model.branch_streams is False
