@@ -1,9 +1,9 @@
 # Concurrency profile of the GRAPH-REPLAYED step with the sub-network forks on and off (tools/trace_overlap.py): kernel trace
-# of bench.py's replay loop, last three steps.  Two bench runs of ~1.5 min each; writes gpurun_out/overlap_forks_{on,off}.{txt,json}.
+# of bench.py's replay loop, last three steps.  Arguments: the settings to run (default "1 0"); one bench run of ~1.5 min each; writes gpurun_out/overlap_forks_{on,off}.{txt,json}.
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for forks in 1 0; do
+for forks in ${@:-1 0}; do
   tag=$([ $forks = 1 ] && echo on || echo off)
   rm -rf /tmp/trace_overlap_$tag
   export TD_BRANCH_STREAMS=$forks

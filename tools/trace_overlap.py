@@ -13,6 +13,11 @@ show that; this tool reads the per-dispatch start / end timestamps and reports, 
   at depth k    time with exactly k kernels in flight
   per queue     busy time and launches of every Queue_Id / Stream_Id the trace names (graph branches land on several)
 
+Measured caveat (profiles/r04/overlap_forks_on_v1.txt): rocprofv3's kernel tracing serialises the dispatches of a graph's parallel
+branches on this stack (one kernel in flight for 94 % of the span, the traced step takes 45 ms against 27 ms untraced), so under the
+tracer busy ~ sum and the overlap itself has to be read from ms_per_step with the forks on / off; what the trace does give is the
+split of the kernel time over the branches (per queue).
+
 Steps are delimited like tools/kstats_from_trace.py does: by the identity-term kernel (td::photo_fwd_kernel<*, 0, *>), which
 runs exactly once per step; only the last N complete steps are counted.
 
