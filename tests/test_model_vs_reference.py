@@ -77,6 +77,59 @@ def _inputs(B, H, W):
 @pytest.mark.parametrize("name", ["mono_fm_joint_inpaint_disentangle", "mono_fm",
                                   "mono_fm_joint_inpaint_disentangle_distill_sep_colorize"])
 def test_same_weights_same_losses(name):
+    _compare(name, {})
+
+
+# the option sets of the BASELINE configs that the 18-layer default above does not cover
+CONFIG_OPTION_SETS = {
+    # config/cfg_kitti_tripleD.py (C2-C4): ResNet50 depth encoder and feature auto-encoder (Bottleneck blocks, 2048-channel heads)
+    "C2_resnet50": ("mono_fm_joint_inpaint_disentangle", dict(depth_num_layers=50, extractor_num_layers=50)),
+    # config/cfg_kitti_fm_joint_inpaint_disentangle_distill_full_colorize.py (C5): no disentangled layer, the colourisation term
+    # masked by the erased regions, its weights
+    "C5_options": ("mono_fm_joint_inpaint_disentangle_distill_sep_colorize",
+                   dict(disentangle_layers=[False] * 5, use_distill_mask=True, img_reconstruct_weight=1, colorize_weight=5e-3)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CONFIG_OPTION_SETS))
+def test_config_option_sets_match_the_reference(case):
+    name, overrides = CONFIG_OPTION_SETS[case]
+    _compare(name, overrides)
+
+
+# the other switches of the reference's model options that this build's classes implement (reference: mono_fm_joint_inpaint/net.py),
+# each against the real class with the same weights: losses, disparities, arg-min selection and every parameter gradient
+TRIPLED, COLORIZE = "mono_fm_joint_inpaint_disentangle", "mono_fm_joint_inpaint_disentangle_distill_sep_colorize"
+REFERENCE_OPTION_SETS = {
+    "base_inpaint_class": ("mono_fm_joint_inpaint", {}),                                             # :20-133
+    "use_pfp": (TRIPLED, dict(use_pfp=True)),                                                        # :405, :502-506 pose from the restored image
+    "depth_use_shuffle": (TRIPLED, dict(depth_use_shuffle=True)),                                    # :444-447, depth_decoder.py:65-104
+    "freeze_extractor": (TRIPLED, dict(freeze_extractor=True)),                                      # :24-27
+    "skip_1x1": (TRIPLED, dict(depth_skip_type="1x1", color_skip_type="1x1", color_skip_layers=[True] * 4)),   # :434, :451, :485
+    "all_layers_disentangled": (TRIPLED, dict(disentangle_layers=[True] * 5, depth_skip_type="use_half", color_skip_type="use_half",
+                                              color_skip_layers=[True] * 4)),                        # :419-426
+    "no_automask_no_disp_norm": (TRIPLED, dict(automask=False, disp_norm=False)),                    # the stereo configs' switches, :101-131
+    "no_image_reconstruction": (TRIPLED, dict(img_reconstruct_weight=0)),                            # :80-91 skipped
+    # attention gates on the depth skips (:410-436; this build: mono/model/attention.py): channel, pixel, both-moments, and in front
+    # of a disentangled half / a learned (1x1 conv + BatchNorm + ELU) half
+    "skip_channel_attention": (TRIPLED, dict(depth_skip_type="ca")),
+    "skip_pixel_attention": (TRIPLED, dict(depth_skip_type="pa")),
+    "skip_moment_attention_all_levels_split": (TRIPLED, dict(depth_skip_type="asca", disentangle_layers=[True] * 5,
+                                                             color_skip_type="use_half", color_skip_layers=[True] * 4)),
+    "skip_attention_learned_halves": (TRIPLED, dict(depth_skip_type="ca", depth_disentangle_type="conv",
+                                                    disentangle_layers=[False, True, False, True, True])),
+    # (cond_encoder with a disentangled last layer fails inside the REFERENCE itself: encoder.py:46 adds 512 and 256 channels)
+    "cond_encoder": (COLORIZE, dict(cond_encoder=True, disentangle_layers=[False] * 5)),             # :296-299, :364-367
+}
+
+
+@pytest.mark.parametrize("case", sorted(REFERENCE_OPTION_SETS))
+def test_model_switches_match_the_reference(case):
+    name, overrides = REFERENCE_OPTION_SETS[case]
+    _compare(name, overrides)
+
+
+def _compare(name, overrides):
     import tripled_amd  # noqa: F401
     classes, NoiseTap, cuda_orig = _reference_classes()
     try:
@@ -84,8 +137,8 @@ def test_same_weights_same_losses(name):
         from oracle.backend import OracleLossBackend
         B, H, W = 2, 96, 128
         torch.manual_seed(3)
-        ref = classes[name](_options(name, B, H, W))
-        mine = MONO.module_dict[name](_options(name, B, H, W))
+        ref = classes[name](Opt(_options(name, B, H, W), **overrides))
+        mine = MONO.module_dict[name](Opt(_options(name, B, H, W), **overrides))
         missing = mine.load_state_dict(ref.state_dict(), strict=True)   # identical checkpoint keys
         assert not missing.missing_keys and not missing.unexpected_keys
         mine.set_loss_backend(OracleLossBackend())

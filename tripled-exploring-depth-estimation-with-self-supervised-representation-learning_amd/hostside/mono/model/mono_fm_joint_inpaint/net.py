@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from ..registry import MONO
 from ..mono_fm_joint.net import mono_fm_joint, resize_bilinear
+from ..attention import skip_attention
 from ..networks import ColorDecoder, Conv1x1, DepthDecoder, Encoder, IdentityPartial, bn_groups
 from .color_conversions import rgb2lab
 
@@ -145,10 +146,11 @@ class mono_fm_joint_inpaint(mono_fm_joint):
 
 
 def _skip_layer(kind, channels, last):
-    """depth_skip_layer_i for a non-disentangled level (reference :423-437).  The attention
-    variants ('ca', 'pa', 'asca') are ablations no BASELINE config selects."""
-    if kind in ("ca", "pa", "asca"):
-        raise NotImplementedError("depth_skip_type=%r is an ablation variant outside the supported configs" % kind)
+    """depth_skip_layer_i for a non-disentangled level (reference :427-439): an attention gate ('ca', 'pa', 'asca':
+    mono/model/attention.py), a 1x1 conv + BatchNorm + ELU on the last level ('1x1'), the identity otherwise."""
+    gate = skip_attention(kind, channels)
+    if gate is not None:
+        return gate
     if kind == "1x1" and last:
         return nn.Sequential(Conv1x1(channels, channels), nn.BatchNorm2d(channels), nn.ELU())
     return nn.Identity()
@@ -174,12 +176,13 @@ class mono_fm_joint_inpaint_disentangle(mono_fm_joint_inpaint):
         for ind, split in enumerate(opt.disentangle_layers):
             c = int(enc_ch[ind])
             if split:
-                if self.depth_skip_type in ("ca", "pa", "asca"):
-                    _skip_layer(self.depth_skip_type, c, False)
+                # (reference :410-426: the gate, if any, in front of the half that goes to the depth decoder)
+                gate = skip_attention(self.depth_skip_type, c)
+                head = [gate] if gate is not None else []
                 if self.depth_disentangle_type == "use_half":
-                    layer = nn.Sequential(IdentityPartial(part_ratio=2, use_right=False))
+                    layer = nn.Sequential(*head, IdentityPartial(part_ratio=2, use_right=False))
                 else:
-                    layer = nn.Sequential(Conv1x1(c, c // 2), nn.BatchNorm2d(c // 2), nn.ELU())
+                    layer = nn.Sequential(*head, Conv1x1(c, c // 2), nn.BatchNorm2d(c // 2), nn.ELU())
                 depth_ch.append(c // 2)
             else:
                 layer = _skip_layer(self.depth_skip_type, c, ind == n_levels - 1)
