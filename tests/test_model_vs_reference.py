@@ -32,11 +32,12 @@ def _reference_classes():
         import importlib
         inpaint = importlib.import_module("mono.model.mono_fm_joint_inpaint.net")
         fm = importlib.import_module("mono.model.mono_fm.net")
+        joint = importlib.import_module("mono.model.mono_fm_joint.net")
         classes = {"mono_fm_joint_inpaint_disentangle": inpaint.mono_fm_joint_inpaint_disentangle,
                    "mono_fm_joint_inpaint": inpaint.mono_fm_joint_inpaint,
                    "mono_fm_joint_inpaint_disentangle_distill_sep_colorize":
                        inpaint.mono_fm_joint_inpaint_disentangle_distill_sep_colorize,
-                   "mono_fm": fm.mono_fm}
+                   "mono_fm": fm.mono_fm, "mono_fm_joint": joint.mono_fm_joint}
         tap = gen_golden.NoiseTap
     finally:
         for k in [k for k in sys.modules if k == "mono" or k.startswith("mono.")]:
@@ -101,6 +102,7 @@ def test_config_option_sets_match_the_reference(case):
 # each against the real class with the same weights: losses, disparities, arg-min selection and every parameter gradient
 TRIPLED, COLORIZE = "mono_fm_joint_inpaint_disentangle", "mono_fm_joint_inpaint_disentangle_distill_sep_colorize"
 REFERENCE_OPTION_SETS = {
+    "joint_class": ("mono_fm_joint", {}),                                                            # mono_fm_joint/net.py (cfg_kitti_fm_joint.py)
     "base_inpaint_class": ("mono_fm_joint_inpaint", {}),                                             # :20-133
     "use_pfp": (TRIPLED, dict(use_pfp=True)),                                                        # :405, :502-506 pose from the restored image
     "depth_use_shuffle": (TRIPLED, dict(depth_use_shuffle=True)),                                    # :444-447, depth_decoder.py:65-104
