@@ -29,9 +29,10 @@ def _one_stream_in_the_long_test_process():
     parity; the forked step captured and replayed is tested through bench.py in a fresh process, the way the product runs it).
     Reason: replaying a forked graph that was captured ~300 tests into the pytest process segfaulted inside hipGraphLaunch
     (tests/test_hip_graph_step.py, first replay; the same test alone, bench.py and the train.py path replay their forked graphs
-    without fault).  Probable cause (a pooled torch.cuda.Stream() aliasing the cached side stream) removed in streams.side_stream and
-    pinned by tests/test_streams_cpu.py + test_hip_streams.py; the confirming full-suite run with the forks on did not fit round 4's GPU
-    budget, so this default stays until it has been done once -- DESIGN.md section 13."""
+    without fault).  The cause is NOT established: a stream-aliasing defect found on the way is fixed and pinned
+    (streams.side_stream; tests/test_streams_cpu.py, test_hip_streams.py), but the minimal negative control -- the pre-fix self-wait,
+    captured and replayed -- does not fault either (tools/diag_self_wait_capture.py).  Until a full-suite run with the forks on has
+    been done and read, this default stays -- DESIGN.md section 13."""
     try:
         import tripled_amd  # noqa: F401
         from tripled_amd import streams

@@ -32,8 +32,9 @@ def side_stream(device, idx, avoid=()):
     """The cached side stream ``idx`` of ``device`` -- never one of ``avoid`` and never another index's stream.
     torch.cuda.Stream() hands out a pool of 32 HIP streams per device round-robin, so a stream created here can BE the stream
     the caller is on (a capture stream created 32 creations later): forking onto the current stream would record an event on
-    a stream and make the same stream wait for it, which inside a capture gives the next node the same dependency twice --
-    hipGraphLaunch of such a graph segfaulted (round 4: tests/test_hip_graph_step.py after ~300 other tests in the process)."""
+    a stream and make the same stream wait for it, and the "branch" would run in line with its caller.  (Found while looking
+    for the cause of a hipGraphLaunch segfault ~300 tests into the GPU suite of round 4; a minimal self-wait capture replays
+    fine -- tools/diag_self_wait_capture.py --, so this defect is fixed but not shown to be that cause: DESIGN.md section 13.)"""
     index = device.index if device.index is not None else torch.cuda.current_device()
     key = (index, idx)
     taken = {int(a.cuda_stream) for a in avoid} | {int(v.cuda_stream) for k, v in _side.items() if k[0] == index and k != key}
