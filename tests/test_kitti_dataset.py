@@ -37,3 +37,30 @@ def test_kitti_triplet_contract(tmp_path):
     first = KITTIRAWDataset(str(tmp_path), files, 32, 96, [0, -1, 1], is_train=False, img_ext=".png")[0]
     assert torch.equal(first[("color", -1, 0)], first[("color", 0, 0)])
     assert ds.flag.shape == (4,)
+
+
+def test_erase_masks_consume_the_generator_like_the_reference():
+    """KITTIInpaintDataset.preprocess_masks (reference kitti_dataset.py:167-182) draws `erase_count` (row, col) pairs with
+    torch.LongTensor(1).random_(0, size - erase - 1) from the global generator; the mirror draws with torch.randint.  Same seed ->
+    the same rectangles (the draw sequence is restated here from the reference's lines; its module needs torchvision / cv2 and
+    cannot be imported in this image), and erase_count == 1 is the reference's centred square."""
+    import types
+    shape, eh, ew, count = (3, 192, 640), 16, 16, 16
+    for seed in (0, 5, 123):
+        fake = types.SimpleNamespace(cfg=ConfigDict(erase_shape=[eh, ew], erase_count=count))
+        inputs = {("color", 0, 0): torch.zeros(shape)}
+        torch.manual_seed(seed)
+        KITTIInpaintDataset.postprocess(fake, inputs)
+        expected = torch.ones(shape, dtype=torch.uint8)
+        torch.manual_seed(seed)
+        for _ in range(count):
+            row = torch.LongTensor(1).random_(0, shape[1] - eh - 1)[0]
+            col = torch.LongTensor(1).random_(0, shape[2] - ew - 1)[0]
+            expected[:, row:row + eh, col:col + ew] = 0
+        assert torch.equal(inputs[("mask", 0, 0)], expected), seed
+    fake = types.SimpleNamespace(cfg=ConfigDict(erase_shape=[64, 64], erase_count=1))
+    inputs = {("color", 0, 0): torch.zeros(shape)}
+    KITTIInpaintDataset.postprocess(fake, inputs)
+    centre = torch.ones(shape, dtype=torch.uint8)
+    centre[:, 64:128, 64:128] = 0                       # offset = (192 - 64) / 2 on BOTH axes, as the reference computes it
+    assert torch.equal(inputs[("mask", 0, 0)], centre)
