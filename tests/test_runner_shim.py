@@ -28,7 +28,10 @@ def test_shipped_configs_load(name):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/config"), reason="reference checkout not present")
 @pytest.mark.parametrize("name", ["cfg_kitti_tripleD", "cfg_kitti_fm",
-                                  "cfg_kitti_fm_joint_inpaint_disentangle_distill_full_colorize"])
+                                  "cfg_kitti_fm_joint_inpaint_disentangle_distill_full_colorize",
+                                  # the reference's other configs whose model class this build registers
+                                  "cfg_kitti_fm_joint", "cfg_kitti_fm_joint_inpaint", "cfg_kitti_fm_joint_inpaint_disentangle",
+                                  "cfg_kitti_fm_refine"])
 def test_reference_configs_drop_in(name):
     """The reference's own config files load unchanged and build the model (tiny override of the
     ResNet depth only to keep the CPU test fast)."""
