@@ -4,6 +4,7 @@ the product backend itself refuses CPU tensors (see tests/test_abi.py)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import tripled_amd  # noqa: F401
@@ -45,3 +46,38 @@ def test_eval_protocol_known_answers():
     assert compute_errors(gt.ravel(), gt.ravel()) == (0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0)
     r = evaluate_disparity((1.0 / (gt * 0.5)).astype(np.float32), gt)
     assert abs(r["scale"] - 2.0) < 1e-4 and r["abs_rel"] < 1e-5 and r["a1"] == 1.0
+
+
+REF_CONFIGS = "/root/reference/config"
+
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference checkout not present")
+@pytest.mark.parametrize("name", ["cfg_kitti_tripleD", "cfg_kitti_fm", "cfg_kitti_fm_joint_inpaint_disentangle_distill_full_colorize",
+                                  "cfg_kitti_fm_joint", "cfg_kitti_fm_joint_inpaint", "cfg_kitti_fm_joint_inpaint_disentangle"])
+def test_reference_config_files_train_one_iteration_on_the_host(name):
+    """The reference's OWN config file (unchanged; only the ResNet depths and the image size are reduced for the CPU) through
+    this build's batch_processor: every loss entry finite, every trainable parameter the config's switches leave in the graph
+    receives a gradient.  (At 64x128 the level-4 feature map is 2x4 and the second-order regulariser averages an empty tensor:
+    NaN in the reference too -- hence 96x160.)"""
+    cfg = Config.fromfile(os.path.join(REF_CONFIGS, name + ".py"))
+    m = cfg.model
+    for k in list(m.keys()):
+        if k.endswith("pretrained_path"):
+            m[k] = None
+    for k in ("depth_num_layers", "pose_num_layers", "extractor_num_layers", "colorize_num_layers"):
+        if k in m:
+            m[k] = 18
+    B, H, W = 1, 96, 160
+    m["imgs_per_gpu"], m["height"], m["width"] = B, H, W
+    torch.manual_seed(0)
+    model = MONO.module_dict[m["name"]](m)
+    model.set_loss_backend(OracleLossBackend())
+    model.train()
+    out = batch_processor(model, synthetic_batch(B, H, W, seed=1, frame_ids=tuple(m["frame_ids"])), train_mode=True)
+    assert out["num_samples"] == B and torch.isfinite(out["loss"])
+    assert all(np.isfinite(v) for v in out["log_vars"].values()), out["log_vars"]
+    out["loss"].backward()
+    with_grad = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+    assert len(with_grad) > 150
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
