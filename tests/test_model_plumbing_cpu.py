@@ -54,7 +54,8 @@ REF_CONFIGS = "/root/reference/config"
 
 @pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference checkout not present")
 @pytest.mark.parametrize("name", ["cfg_kitti_tripleD", "cfg_kitti_fm", "cfg_kitti_fm_joint_inpaint_disentangle_distill_full_colorize",
-                                  "cfg_kitti_fm_joint", "cfg_kitti_fm_joint_inpaint", "cfg_kitti_fm_joint_inpaint_disentangle"])
+                                  "cfg_kitti_fm_joint", "cfg_kitti_fm_joint_inpaint", "cfg_kitti_fm_joint_inpaint_disentangle",
+                                  "cfg_kitti_fm_refine"])        # (frame_ids [0, -1, 1, 's']: the stereo pair, no auto-mask)
 def test_reference_config_files_train_one_iteration_on_the_host(name):
     """The reference's OWN config file (unchanged; only the ResNet depths and the image size are reduced for the CPU) through
     this build's batch_processor: every loss entry finite, every trainable parameter the config's switches leave in the graph
@@ -74,7 +75,12 @@ def test_reference_config_files_train_one_iteration_on_the_host(name):
     model = MONO.module_dict[m["name"]](m)
     model.set_loss_backend(OracleLossBackend())
     model.train()
-    out = batch_processor(model, synthetic_batch(B, H, W, seed=1, frame_ids=tuple(m["frame_ids"])), train_mode=True)
+    batch = synthetic_batch(B, H, W, seed=1, frame_ids=tuple(m["frame_ids"]))
+    if "s" in m["frame_ids"]:
+        stereo_T = torch.eye(4).repeat(B, 1, 1)
+        stereo_T[:, 0, 3] = -0.015                   # left camera, no flip (mono_dataset.py:194-199)
+        batch["stereo_T"] = stereo_T
+    out = batch_processor(model, batch, train_mode=True)
     assert out["num_samples"] == B and torch.isfinite(out["loss"])
     assert all(np.isfinite(v) for v in out["log_vars"].values()), out["log_vars"]
     out["loss"].backward()

@@ -58,13 +58,18 @@ def _options(name, B, H, W):
     return o
 
 
-def _inputs(B, H, W):
+def _inputs(B, H, W, stereo=False):
     from tests.util import kitti_K, make_triplet
     g = torch.Generator().manual_seed(0)
     fr = make_triplet(g, B, H, W)
     K, iK = kitti_K(B, H, W)
     inputs = {}
-    for f in (0, -1, 1):
+    if stereo:      # the other camera of the rig: the target shifted by a few pixels, and the rig's extrinsics (mono_dataset.py:194-199)
+        fr["s"] = torch.roll(fr[0], 3, dims=3).contiguous()
+        stereo_T = torch.eye(4).repeat(B, 1, 1)
+        stereo_T[:, 0, 3] = -0.015
+        inputs["stereo_T"] = stereo_T
+    for f in fr:
         inputs[("color", f, 0)] = fr[f]
         inputs[("color_aug", f, 0)] = (fr[f] * 0.9 + 0.03).contiguous()
     mask = torch.ones(B, 3, H, W)
@@ -120,6 +125,10 @@ REFERENCE_OPTION_SETS = {
                                                              color_skip_type="use_half", color_skip_layers=[True] * 4)),
     "skip_attention_learned_halves": (TRIPLED, dict(depth_skip_type="ca", depth_disentangle_type="conv",
                                                     disentangle_layers=[False, True, False, True, True])),
+    # the stereo pair as a fourth frame with the rig's fixed transform instead of a predicted pose (mono_fm_joint/net.py:164-179, :186-189;
+    # cfg_kitti_fm_refine.py: frame_ids [0, -1, 1, 's'] switches auto-mask and disparity normalisation off)
+    "stereo_frame_fm": ("mono_fm", dict(frame_ids=[0, -1, 1, "s"], automask=False, disp_norm=False)),
+    "stereo_frame_tripled": (TRIPLED, dict(frame_ids=[0, -1, 1, "s"], automask=False, disp_norm=False)),
     # (cond_encoder with a disentangled last layer fails inside the REFERENCE itself: encoder.py:46 adds 512 and 256 channels)
     "cond_encoder": (COLORIZE, dict(cond_encoder=True, disentangle_layers=[False] * 5)),             # :296-299, :364-367
 }
@@ -147,12 +156,13 @@ def _compare(name, overrides):
         for m in (ref, mine):
             m.train()
             m.DepthDecoder.do.eval()          # dropout is the one RNG consumer we do not replay
-        ref_in = _inputs(B, H, W)
+        stereo = "s" in overrides.get("frame_ids", ())
+        ref_in = _inputs(B, H, W, stereo)
         with NoiseTap() as tap:
             ref_out, ref_loss = ref(ref_in)
         draws = list(tap.draws)
         mine.set_noise_source(lambda shape, device: draws.pop(0))
-        out, loss = mine(_inputs(B, H, W))
+        out, loss = mine(_inputs(B, H, W, stereo))
         assert [str(k) for k in loss] == [str(k) for k in ref_loss]
         for k in ref_loss:
             a, b = loss[k].mean(), ref_loss[k].mean()
