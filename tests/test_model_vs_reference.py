@@ -185,5 +185,14 @@ def _compare(name, overrides):
             assert float((p.grad - rg).abs().max()) <= 2e-3 * scale + 1e-9, n
             checked += 1
         assert checked > 100
+        # inference (model.eval(): running BatchNorm statistics, which the training pass above has just updated on both sides;
+        # the forward returns the outputs only -- reference mono_fm_joint_inpaint/net.py:477-499, mono_fm/net.py:53-66)
+        ref.eval()
+        mine.eval()
+        with torch.no_grad():
+            ref_eval, my_eval = ref(_inputs(B, H, W, stereo)), mine(_inputs(B, H, W, stereo))
+        assert isinstance(my_eval, dict) and isinstance(ref_eval, dict)
+        for s in range(4):
+            assert float((my_eval[("disp", 0, s)] - ref_eval[("disp", 0, s)]).abs().max()) < 1e-5, s
     finally:
         torch.Tensor.cuda = cuda_orig
