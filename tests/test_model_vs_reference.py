@@ -152,6 +152,10 @@ def _compare(name, overrides):
         mine = MONO.module_dict[name](Opt(_options(name, B, H, W), **overrides))
         missing = mine.load_state_dict(ref.state_dict(), strict=True)   # identical checkpoint keys
         assert not missing.missing_keys and not missing.unexpected_keys
+        # ... and the same parameter ORDER: a checkpoint's optimiser state is indexed by position in model.parameters()
+        # (torch.optim state_dict), so resuming a reference run needs the registration order, not just the names
+        assert [n for n, _ in mine.named_parameters()] == [n for n, _ in ref.named_parameters()]
+        assert list(mine.state_dict()) == list(ref.state_dict())          # (this build's extra buffers are non-persistent)
         mine.set_loss_backend(OracleLossBackend())
         for m in (ref, mine):
             m.train()
