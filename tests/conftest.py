@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A per-test ceiling (pytest-timeout, where installed: it is in this image): the multi-process tests wait on children
+    (mp.spawn / subprocess) and a rank that never arrives would otherwise hold the whole run until the driver's own limit.
+    25 minutes is far above the slowest test (a bench.py child with its own 900 s limit)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(1500))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
