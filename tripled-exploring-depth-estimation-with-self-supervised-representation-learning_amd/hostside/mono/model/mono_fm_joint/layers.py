@@ -9,6 +9,8 @@ import torch.nn.functional as F
 
 from ..networks import (Conv1x1, Conv3x3, Conv5x5, ConvBlock, CRPBlock, IdentityPartial,  # noqa: F401
                         upsample, upshuffle)
+from ..attention import (AdaptivelyScaledCALayer, CALayer, ChannelDescriptorLayer,  # noqa: F401  (layers.py:232-243, 283-385)
+                         SqueezeAndExcitationBlock)
 
 
 def disp_to_depth(disp, min_depth, max_depth):
