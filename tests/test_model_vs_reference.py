@@ -200,3 +200,46 @@ def _compare(name, overrides):
             assert float((my_eval[("disp", 0, s)] - ref_eval[("disp", 0, s)]).abs().max()) < 1e-5, s
     finally:
         torch.Tensor.cuda = cuda_orig
+
+
+@pytest.mark.parametrize("name", ["mono_fm", COLORIZE])
+def test_initialisation_follows_the_reference_schemes(name):
+    """Training from scratch starts from the same distributions: every tensor the reference initialises to a constant (BatchNorm
+    scales and shifts, running statistics, zeroed biases) is that constant here, and every random tensor has the reference's
+    standard deviation (kaiming / PyTorch-default fans; sampling noise of two independent draws allowed: 8 % on >= 2048 elements).
+    Same seed -> same DRAWS holds only up to the first sub-network built twice by the reference's class hierarchy (the parent
+    constructor's DepthDecoder / the 3-channel stem the pose encoder replaces consume generator state): checked for the depth
+    encoder, which both build first."""
+    import tripled_amd  # noqa: F401
+    classes, _, cuda_orig = _reference_classes()
+    try:
+        from mono.model import MONO
+        ov = dict(depth_num_layers=50, extractor_num_layers=50)
+        torch.manual_seed(7)
+        ref = classes[name](Opt(_options(name, 2, 96, 128), **ov))
+        torch.manual_seed(7)
+        mine = MONO.module_dict[name](Opt(_options(name, 2, 96, 128), **ov))
+        sa, sb = ref.state_dict(), mine.state_dict()
+        assert list(sa) == list(sb)
+        random_tensors = 0
+        for k in sa:
+            x, y = sa[k].float(), sb[k].float()
+            assert x.shape == y.shape, k
+            if k.startswith("DepthEncoder."):
+                assert torch.equal(x, y), k                       # same seed, same draws
+                continue
+            if x.numel() == 1:
+                if not sa[k].is_floating_point():
+                    assert torch.equal(x, y), k                   # num_batches_tracked
+                continue                                          # (a one-element random bias: nothing to compare)
+            if float(x.std()) == 0.0:
+                assert torch.equal(x, y), k                       # constants
+                continue
+            if x.numel() >= 2048:
+                ratio = float(y.std()) / float(x.std())
+                assert abs(ratio - 1) < 0.08, (k, float(x.std()), float(y.std()))
+                assert abs(float(y.mean()) - float(x.mean())) < 0.1 * float(x.std()), k
+                random_tensors += 1
+        assert random_tensors > 100
+    finally:
+        torch.Tensor.cuda = cuda_orig
