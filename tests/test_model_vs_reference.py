@@ -140,13 +140,19 @@ def test_model_switches_match_the_reference(case):
     _compare(name, overrides)
 
 
-def _compare(name, overrides):
+@pytest.mark.parametrize("shape", [(1, 128, 192), (3, 96, 320)])
+def test_other_batch_and_image_shapes_match_the_reference(shape):
+    """One image per step / a wide 1:3.3 frame like KITTI's (the default cases run 2 x 96 x 128)."""
+    _compare(TRIPLED, {}, shape)
+
+
+def _compare(name, overrides, shape=(2, 96, 128)):
     import tripled_amd  # noqa: F401
     classes, NoiseTap, cuda_orig = _reference_classes()
     try:
         from mono.model import MONO
         from oracle.backend import OracleLossBackend
-        B, H, W = 2, 96, 128
+        B, H, W = shape
         torch.manual_seed(3)
         ref = classes[name](Opt(_options(name, B, H, W), **overrides))
         mine = MONO.module_dict[name](Opt(_options(name, B, H, W), **overrides))
